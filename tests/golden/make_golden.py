@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the reference's own Python.
+
+Run ONCE in the build container (needs /root/reference; the GPU box has neither
+the reference nor a need to run this):
+
+    MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is imported from /root/reference and called (file:line of the callee):
+  FX1  helpers/FeatureExtractor.py:30   Read_Landmarks_and_Normalizing_using_IPD
+  FX2  NLML_HPE_Model_Builder.py:71     AnglePredictionNetwork (+ shipped models/*.pth)
+  FX3  NLML_HPE_Model_Builder.py:26,107 LandmarkEncoder, CombinedAnglePredictionModel (eager + jit.script)
+  FX4  TD_Tester.py:31                  objective (and the same einsum for x_hat)
+  FX5  TD_Tester.py:162                 Test (scipy Powell)
+  FX6  NLML_HPE_Test.py:62,95           compute_maev, compute_errors
+  FX7  generatePose_on_video.py:73,128  visualize_axes_on_face, process_video (EMA loop)
+
+cv2 / mediapipe are not installed; empty stub modules satisfy the imports, and
+for FX7 the handful of cv2 / FaceMesh entry points process_video touches are
+replaced by recording fakes so the reference's own frame loop runs on synthetic
+landmarks.  Nothing of the reference's source is written to the fixtures: they
+hold inputs, seeds and the numbers the reference returned.
+
+Inputs come from nlml_hpe_amd.synth (Philox), so tests can regenerate them.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(1, REF)
+sys.dont_write_bytecode = True
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+for _n in ("cv2", "mediapipe", "utils", "tensorly"):
+    sys.modules.setdefault(_n, types.ModuleType(_n))
+
+import torch  # noqa: E402
+
+from nlml_hpe_amd import synth  # noqa: E402
+
+torch.set_num_threads(1)  # fixture values independent of the thread count of this box
+
+
+class _LM:
+    """Duck-typed MediaPipe landmark: .x/.y/.z are Python floats of f32 values."""
+    __slots__ = ("x", "y", "z")
+
+    def __init__(self, p):
+        self.x, self.y, self.z = float(p[0]), float(p[1]), float(p[2])
+
+
+def fx1_normalise():
+    from helpers import FeatureExtractor as FE
+    lm = synth.raw_landmarks(16, seed=11)
+    lm[3, 263] = lm[3, 33]                 # ipd == 0 -> 1e-6 branch (FeatureExtractor.py:47-48)
+    lm[4] *= 1e-3                          # tiny face
+    lm[5] = lm[5] * 1920.0                 # pixel-scale coordinates
+    lm[6, 33] = lm[6, 263] + np.float32(1e-7)  # near-degenerate ipd
+    out_norm = np.empty((16, 1404), np.float32)
+    out_raw = np.empty((16, 1404), np.float32)
+    for b in range(16):
+        lms = [_LM(p) for p in lm[b]]
+        ref = [lms[1].x, lms[1].y, lms[1].z]                              # FeatureExtractor.py:85-86
+        l1 = FE.Read_Landmarks_and_Normalizing_using_IPD(lms, ref, True)
+        l0 = FE.Read_Landmarks_and_Normalizing_using_IPD(lms, ref, False)
+        out_norm[b] = torch.tensor(l1[0:1404]).float().numpy()            # :101
+        out_raw[b] = torch.tensor(l0[0:1404]).float().numpy()
+    np.savez_compressed(os.path.join(HERE, "fx1_normalise.npz"), landmarks=lm, features_norm=out_norm, features_raw=out_raw)
+    print("FX1", out_norm.shape, float(np.abs(out_norm).max()))
+
+
+def _load_heads(MB):
+    heads = {}
+    for n in ("yaw", "pitch", "roll"):
+        net = MB.AnglePredictionNetwork(3)
+        net.load_state_dict(torch.load(os.path.join(REF, "models", f"{n}_network.pth"), map_location="cpu"))
+        heads[n] = net.eval()
+    return heads
+
+
+def fx2_heads():
+    import NLML_HPE_Model_Builder as MB
+    import TD_Tester
+    heads = _load_heads(MB)
+    fm = np.load(os.path.join(REF, "outputs/features/Factor_Matrices.npz"))
+    td = np.load(os.path.join(REF, "outputs/features/Trained_data.npz"))
+    out = {}
+    for n in ("yaw", "pitch", "roll"):
+        U = fm[f"U_{n}"].astype(np.float32)
+        P = td[f"optimized_{n}"]
+        w = np.radians(np.linspace(-60, 60, 49))
+        sweep = np.array([[TD_Tester.func(wi, p) for p in P] for wi in w]).astype(np.float32)   # cosine curves
+        z = np.concatenate([U, sweep, np.zeros((1, 3), np.float32)], axis=0)
+        with torch.no_grad():
+            y = heads[n](torch.from_numpy(z)).numpy()
+        out[f"in_{n}"] = z
+        out[f"out_{n}"] = y
+    np.savez_compressed(os.path.join(HERE, "fx2_heads.npz"), **out)
+    print("FX2", {k: v.shape for k, v in out.items()})
+
+
+def fx3_encoder_heads():
+    import NLML_HPE_Model_Builder as MB
+    heads = _load_heads(MB)
+    out = {}
+    for F in (1404, 136):
+        enc = MB.LandmarkEncoder(F, [(1, 3)] * 3)
+        sd = {k: torch.from_numpy(v) for k, v in synth.encoder_state_dict(F, seed=0).items()}
+        enc.load_state_dict(sd)
+        model = MB.CombinedAnglePredictionModel(enc, heads["yaw"], heads["pitch"], heads["roll"]).eval()
+        x = synth.features(256, F, seed=1)
+        x[7] = 0.0            # the all-zero "no face" row still flows through the reference's forward
+        with torch.no_grad():
+            y = torch.cat(model(torch.from_numpy(x)), dim=1).numpy()
+            ys = torch.cat(torch.jit.script(model)(torch.from_numpy(x)), dim=1).numpy()
+            y1 = torch.cat([torch.cat(model(torch.from_numpy(x[i:i + 1])), dim=1) for i in range(16)]).numpy()
+        assert np.array_equal(y, ys), "eager != scripted"
+        out[f"rad_F{F}"] = y
+        out[f"rad_b1_F{F}"] = y1          # batch-1 calls, the way the reference runs (NLML_HPE_Test.py:262-272)
+        out[f"x_crc_F{F}"] = np.array([float(x.astype(np.float64).sum()), float(np.abs(x).astype(np.float64).sum())])
+        print("FX3", F, y.shape, np.degrees(np.abs(y).max()), "b1 vs batched max|d| deg", np.degrees(np.abs(y[:16] - y1).max()))
+    np.savez_compressed(os.path.join(HERE, "fx3_encoder_heads.npz"), **out)
+
+
+def _tucker_inputs(n, seed):
+    from oracle import tucker as OT
+    td = np.load(os.path.join(REF, "outputs/features/Trained_data.npz"))
+    fm = np.load(os.path.join(REF, "outputs/features/Factor_Matrices.npz"))
+    W = td["W"]
+    idx = synth.tucker_grid_indices(n, seed=seed)
+    g = synth.rng(seed, 77)
+    X = np.stack([
+        OT.grid_reconstruction(W, fm["U_id"][i], fm["U_yaw"][j], fm["U_pitch"][k], fm["U_roll"][l])
+        for i, j, k, l in idx
+    ])
+    X = (X.astype(np.float64) + 1e-3 * g.standard_normal(X.shape)).astype(np.float32)
+    return td, fm, W, idx, X
+
+
+def fx4_td_objective():
+    import TD_Tester
+    n = 32
+    td, fm, W, idx, X = _tucker_inputs(n, seed=2)
+    P = synth.tucker_params(n, 5, seed=2)
+    P[0] = 0.0                                  # the optimiser's starting point (TD_Tester.py:166)
+    Py, Pp, Pr = td["optimized_yaw"][0:3, :], td["optimized_pitch"][0:3, :], td["optimized_roll"][0:3, :]
+    err = np.empty(n)
+    xh = np.empty((8, 1404))
+    for i in range(n):
+        err[i] = TD_Tester.objective(P[i], W, torch.from_numpy(X[i]), Py, Pp, Pr)
+        if i < 8:
+            w_y, w_p, w_r = P[i][:3]
+            f_y = np.array([TD_Tester.func(w_y, p) for p in Py]).flatten().astype(np.float32)
+            f_p = np.array([TD_Tester.func(w_p, p) for p in Pp]).flatten().astype(np.float32)
+            f_r = np.array([TD_Tester.func(w_r, p) for p in Pr]).flatten().astype(np.float32)
+            xh[i] = np.einsum('ijklm,i,j,k,l->m', W, P[i][3:], f_y, f_p, f_r)      # TD_Tester.py:46
+    np.savez_compressed(os.path.join(HERE, "fx4_td_objective.npz"), params=P, x=X, grid_idx=idx, err=err, x_hat=xh)
+    print("FX4 err range", err.min(), err.max())
+
+
+def fx5_td_end_to_end():
+    import TD_Tester
+    import scipy
+    td = np.load(os.path.join(REF, "outputs/features/Trained_data.npz"))
+    fm = np.load(os.path.join(REF, "outputs/features/Factor_Matrices.npz"))
+    from oracle import tucker as OT
+    W = td["W"]
+    Py, Pp, Pr = td["optimized_yaw"][0:3, :], td["optimized_pitch"][0:3, :], td["optimized_roll"][0:3, :]
+    # grid poses (deg): yaw bins -50..50 step 10, pitch -40..40, roll -30..30 (configs/config_TD_main.yaml)
+    picks = [(100, 7, 2, 4), (0, 5, 4, 3), (700, 0, 8, 6), (1500, 10, 0, 0)]   # (id, yaw-bin, pitch-bin, roll-bin)
+    X, deg, nfev, fun, xs = [], [], [], [], []
+    for (i, j, k, l) in picks:
+        x = OT.grid_reconstruction(W, fm["U_id"][i], fm["U_yaw"][j], fm["U_pitch"][k], fm["U_roll"][l])
+        del TD_Tester.objective_values[:]
+        y, p, r, _ = TD_Tester.Test(W, torch.from_numpy(x), 5, Py, Pp, Pr, None, None, None, None)
+        X.append(x); deg.append((y, p, r)); nfev.append(len(TD_Tester.objective_values))
+        print("FX5", (i, j, k, l), (y, p, r), "nfev", nfev[-1])
+    np.savez_compressed(os.path.join(HERE, "fx5_td_end_to_end.npz"), x=np.stack(X), picks=np.array(picks),
+                        deg=np.array(deg), nfev=np.array(nfev), scipy_version=np.array(scipy.__version__))
+
+
+def fx6_metrics():
+    import NLML_HPE_Test as T
+    gt = synth.poses_deg(64, seed=4)
+    g = synth.rng(4, 99)
+    pred = np.round(gt + 3.0 * g.standard_normal(gt.shape), 3)
+    gt_l = [tuple(map(float, r)) for r in gt]
+    pred_l = [tuple(map(float, r)) for r in pred]
+    maev = T.compute_maev(gt_l, pred_l)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        T.compute_errors(gt_l, pred_l)
+    small_gt = [(10.0, -5.0, 3.0), (-30.0, 20.0, -10.0)]
+    small_pred = [(11.0, -4.0, 2.5), (-28.0, 22.0, -11.0)]
+    small = T.compute_maev(small_gt, small_pred)
+    R, l, b, f = T.W300_EulerAngles2Vectors(12.5, -33.0, 7.25)
+    json.dump({
+        "gt": gt.tolist(), "pred": pred.tolist(), "maev": list(map(float, maev)),
+        "printed": buf.getvalue().splitlines(),
+        "small_gt": small_gt, "small_pred": small_pred, "small_maev": list(map(float, small)),
+        "euler_in": [12.5, -33.0, 7.25], "R": R.tolist(), "l": l.tolist(), "b": b.tolist(), "f": f.tolist(),
+    }, open(os.path.join(HERE, "fx6_metrics.json"), "w"), indent=1)
+    print("FX6", maev, small)
+
+
+def fx7_video_math():
+    """Run the reference's own process_video loop on synthetic landmarks with recording fakes."""
+    import cv2
+    import mediapipe as mp
+    from helpers import FeatureExtractor as FE
+    import generatePose_on_video as V
+
+    T, Wpx, Hpx = 48, 1920, 1080
+    g = synth.rng(7, 0)
+    # smooth pose trajectory (radians) the fake model returns, one per frame
+    t = np.linspace(0, 1, T)
+    pose_rad = np.stack([0.6 * np.sin(2 * np.pi * t), 0.4 * np.cos(3 * np.pi * t), 0.3 * np.sin(5 * np.pi * t)], 1).astype(np.float32)
+    lm = synth.raw_landmarks(T, seed=7) * 0.2 + 0.4          # faces near the frame centre
+    lm[20, (1, 33, 263), :2] += 0.5                           # a >100 px jump -> gate keeps previous centre
+    no_face = {5, 6}                                          # frames where FaceMesh "finds nothing"
+
+    class _Res:
+        def __init__(self, lms):
+            self.multi_face_landmarks = lms
+
+    class _Face:
+        def __init__(self, arr):
+            self.landmark = [_LM(p) for p in arr]
+
+    state = {"frame": -1}
+
+    class _FaceMesh:
+        def __init__(self, *a, **k):
+            pass
+
+        def process(self, img):
+            return _Res(None if state["frame"] in no_face else [_Face(lm[state["frame"]])])
+
+    class _Cap:
+        def __init__(self, src):
+            self.i = 0
+
+        def isOpened(self):
+            return True
+
+        def get(self, prop):
+            return {0: 30.0, 1: Wpx, 2: Hpx}[prop]
+
+        def read(self):
+            if self.i >= T:
+                return False, None
+            state["frame"] = self.i
+            self.i += 1
+            return True, np.zeros((Hpx, Wpx, 3), np.uint8)
+
+        def release(self):
+            pass
+
+    cv2.VideoCapture = _Cap
+    cv2.CAP_PROP_FPS, cv2.CAP_PROP_FRAME_WIDTH, cv2.CAP_PROP_FRAME_HEIGHT = 0, 1, 2
+    cv2.COLOR_BGR2RGB = 0
+    cv2.FONT_HERSHEY_SIMPLEX = 0
+    cv2.cvtColor = lambda img, code: img
+    cv2.line = lambda *a, **k: None
+    cv2.putText = lambda *a, **k: None
+    cv2.imshow = lambda *a, **k: None
+    cv2.waitKey = lambda *a, **k: 0
+    cv2.destroyAllWindows = lambda: None
+    mp.solutions = types.SimpleNamespace(face_mesh=types.SimpleNamespace(FaceMesh=_FaceMesh))
+
+    class _Model:
+        def __call__(self, x):
+            p = pose_rad[state["frame"]]
+            return tuple(torch.tensor([[float(v)]]) for v in p)
+
+    rec = []
+    orig = V.visualize_axes_on_face
+
+    def spy(prev_tdx, prev_tdy, max_jump, frame, landmarks, yaw, pitch, roll, size=80):
+        # record what the reference's loop passes in (the EMA-smoothed angles) and what it gets back
+        lines = []
+        cv2.line = lambda fr, p0, p1, col, th: lines.append((p0, p1))
+        out = orig(prev_tdx, prev_tdy, max_jump, frame, landmarks, yaw, pitch, roll, size)
+        rec.append({"frame": state["frame"], "smoothed": [float(yaw), float(pitch), float(roll)],
+                    "prev": [None if prev_tdx is None else float(prev_tdx), None if prev_tdy is None else float(prev_tdy)],
+                    "centre": [float(out[1]), float(out[2])], "lines": [[list(map(int, a)), list(map(int, b))] for a, b in lines]})
+        return out
+
+    V.visualize_axes_on_face = spy
+    with contextlib.redirect_stdout(io.StringIO()):
+        V.process_video("synthetic.avi", None, _Model(), False, "cpu")
+    V.visualize_axes_on_face = orig
+    np.savez_compressed(os.path.join(HERE, "fx7_video_in.npz"), landmarks=lm, pose_rad=pose_rad, no_face=np.array(sorted(no_face)))
+    json.dump({"width": Wpx, "height": Hpx, "frames": rec}, open(os.path.join(HERE, "fx7_video_math.json"), "w"))
+    print("FX7 frames recorded", len(rec), "of", T)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7"]
+    table = {"1": fx1_normalise, "2": fx2_heads, "3": fx3_encoder_heads, "4": fx4_td_objective,
+             "5": fx5_td_end_to_end, "6": fx6_metrics, "7": fx7_video_math}
+    for w in which:
+        table[w]()
