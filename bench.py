@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- faces/sec of the NLML_HPE batched-inference hot path on N MI355X GPUs.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One STEP = one pass of the hot path over one batch that is already resident in HBM:
+raw landmarks f32[B,468,3] -> IPD normalisation -> encoder -> 3 heads -> (yaw,pitch,roll) f32[B,3],
+one fused HIP launch per rank (nlml_landmarks_to_pose), B = 65,536 faces per GPU (weak scaling),
+F = 1404 (the reference's real feature width), f32 parity mode.  With N > 1 every
+step also all-gathers the [B,3] poses of all ranks over RCCL (the only collective the path has),
+on the communication stream, overlapped with the next step's compute.
+
+Prints ONE JSON line (rank 0): the contract fields plus
+  roofline      the fused kernel against the dense f32-MFMA peak (the binding roofline),
+                achieved = algorithmic FLOP per launch / average launch time from HIP events;
+  cpu_baseline  the oracle's torch-CPU restatement of the same arithmetic on this host's cores;
+  extra         secondary workloads (features-in K2, F=136, stand-alone K1, Tucker objective K3).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FLOP_PER_FACE = {1404: 4_714_240, 136: 2_117_376}     # SURVEY.md section 8 table (2 x MACs)
+BYTES_PER_FACE_K2 = {1404: 5_628, 136: 556}            # f32 features in + 3 x f32 out
+BYTES_PER_FACE_K1 = 11_232                             # 5616 read + 5616 written
+PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md, dense f32 matrix
+PEAK_HBM_GBS = 8000.0
+PEAK_F64_TFLOPS = 78.6
+TUCKER_FLOP_PER_EVAL = 383_700
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=65536, help="faces per GPU per step")
+    ap.add_argument("--path", choices=["fused", "features"], default="fused",
+                    help="fused: raw landmarks in (K1+K2 in one launch); features: normalised features in (K2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def time_kernel(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in evs]))  # ms
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from nlml_hpe_amd import ops, synth, weights
+    from nlml_hpe_amd.distributed import PoseGatherer
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", device_id=dev)
+        dist = dist_mod
+
+    F, B = 1404, args.batch
+    heads = weights.load_head_state_dicts(os.path.join(ROOT, "models"))
+    sd = synth.encoder_state_dict(F, seed=0)
+    blob = torch.from_numpy(weights.pack_blob(sd, heads)).to(dev)
+    raw_np = synth.raw_landmarks(B, seed=1 + rank)           # each rank owns its own shard of faces
+    raw = torch.from_numpy(raw_np).to(dev)
+    feats = ops.normalize_ipd(raw, True)
+
+    if args.path == "fused":
+        step_fn = lambda: ops.landmarks_to_pose(raw, blob, True)
+    else:
+        step_fn = lambda: ops.encoder_heads_fwd(feats, blob, F)
+
+    gatherer = PoseGatherer(B, world, dev) if world > 1 else None
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def run_steps(n, events=None):
+        for i in range(n):
+            if events is not None:
+                events[i][0].record()
+            out = step_fn()
+            if events is not None:
+                events[i][1].record()
+            if gatherer is not None:
+                gatherer.submit(out)
+        if gatherer is not None:
+            gatherer.drain()
+
+    run_steps(args.warmup)
+    torch.cuda.synchronize()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps, evs)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kt = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+    kern_ms = float(kt.item())
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        achieved = B * FLOP_PER_FACE[F] / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.path}_bytes_per_launch")
+            except Exception:
+                traffic = None
+        rec = {
+            "metric": "faces_per_sec", "value": value, "unit": "faces/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"landmarks->pose, batch {B}/GPU, F=1404 (468x3 landmarks), encoder+3 heads fused HIP forward, "
+                                   f"f32 parity mode, path={args.path}",
+                       "faces_per_gpu": B, "F": F, "path": args.path, "seeds": {"encoder": 0, "landmarks": "1+rank"},
+                       "collective": "all_gather f32[B,3] per step" if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "kernel": "encoder_heads_f32_kernel", "kernel_ms": kern_ms,
+                         "flop_per_launch": B * FLOP_PER_FACE[F],
+                         "hbm_frac": B * (BYTES_PER_FACE_K2[F]) / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(raw_np, sd, heads, args.cpu_seconds)
+        if world == 1 and not args.no_extra:
+            rec["extra"] = extra_workloads(ops, synth, weights, dev, heads, blob, raw, feats, B)
+        print(json.dumps(rec), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(raw_np, sd, heads, seconds):
+    """The oracle ("port": same ATen ops as the reference's CPU path) on this host's cores."""
+    from oracle import encoder_heads as EH
+    from oracle import feature_norm as FN
+    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(ncores)
+    P = EH.Params(sd, heads)
+    n = 16384
+    x = FN.normalize_ipd(raw_np[:n], True)
+    EH.forward_torch(x[:256], P)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        EH.forward_torch(x, P)
+        done += n
+        if time.perf_counter() - t0 >= seconds:
+            break
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for i in range(64):                                  # the way the reference actually runs: batch 1
+        EH.forward_torch(x[i:i + 1], P)
+    b1 = 64 / (time.perf_counter() - t1)
+    return {"value": done / dt, "unit": "faces/s", "cores": ncores, "kind": "port",
+            "sample": f"{done} faces in batches of {n} (encoder+heads on pre-normalised rows, torch CPU f32, {dt:.1f} s)",
+            "batch1_faces_per_sec": b1}
+
+
+def extra_workloads(ops, synth, weights, dev, heads, blob, raw, feats, B):
+    ex = {}
+    ms = time_kernel(lambda: ops.encoder_heads_fwd(feats, blob, 1404), 10)
+    ex["k2_features_F1404"] = {"faces_per_sec": B / ms * 1e3, "tflops": B * FLOP_PER_FACE[1404] / ms / 1e9,
+                               "mfma_frac": B * FLOP_PER_FACE[1404] / ms / 1e9 / PEAK_F32_MFMA_TFLOPS}
+    sd136 = synth.encoder_state_dict(136, seed=0)
+    blob136 = torch.from_numpy(weights.pack_blob(sd136, heads)).to(dev)
+    x136 = torch.from_numpy(synth.features(B, 136, seed=1)).to(dev)
+    ms = time_kernel(lambda: ops.encoder_heads_fwd(x136, blob136, 136), 10)
+    ex["k2_features_F136"] = {"faces_per_sec": B / ms * 1e3, "tflops": B * FLOP_PER_FACE[136] / ms / 1e9,
+                              "mfma_frac": B * FLOP_PER_FACE[136] / ms / 1e9 / PEAK_F32_MFMA_TFLOPS}
+    ms = time_kernel(lambda: ops.normalize_ipd(raw, True), 20)
+    ex["k1_normalize"] = {"faces_per_sec": B / ms * 1e3, "gbs": B * BYTES_PER_FACE_K1 / ms / 1e6,
+                          "hbm_frac": B * BYTES_PER_FACE_K1 / ms / 1e6 / PEAK_HBM_GBS}
+    art = weights.load_tucker_artefacts(os.path.join(ROOT, "outputs", "features"))
+    cp = torch.from_numpy(np.stack([art["optimized_yaw"][:3], art["optimized_pitch"][:3], art["optimized_roll"][:3]])).to(dev)
+    Wm = torch.from_numpy(art["W"].reshape(135, 1404)).to(dev)
+    N = 4096
+    P = torch.from_numpy(synth.tucker_params(N, 5, seed=2)).to(dev)
+    ms = time_kernel(lambda: ops.tucker_objective(Wm, feats[:N], P, cp), 20)
+    ex["k3_tucker_objective"] = {"evals_per_sec": N / ms * 1e3, "tflops_f64": N * TUCKER_FLOP_PER_EVAL / ms / 1e9,
+                                 "f64_frac": N * TUCKER_FLOP_PER_EVAL / ms / 1e9 / PEAK_F64_TFLOPS, "n": N}
+    return ex
+
+
+if __name__ == "__main__":
+    main()

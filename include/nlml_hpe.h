@@ -1,0 +1,131 @@
+/*
+ * nlml_hpe.h -- C ABI of libnlml_hpe_hip.so: the MI355X (gfx950) implementation of the
+ * NLML_HPE batched-inference hot path.
+ *
+ * The reference (MahdiGhafoorian/NLML_HPE) is pure Python on stock ATen / numpy and has no
+ * FFI of its own; each entry point below names the reference call it replaces (file:line
+ * under /root/reference) so a maintainer can bind it from the same place (ctypes stubs in
+ * INTEGRATION.md).  Conventions for every function:
+ *
+ *   - plain pointers and sizes only; all data pointers are DEVICE pointers unless the
+ *     parameter name starts with "h_" (host);
+ *   - the caller owns every buffer; nothing is allocated or freed inside a launch function;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); launches are
+ *     asynchronous on it and may be captured into a hipGraph;
+ *   - return value 0 on success, otherwise a negative NLML_E_* code or a positive
+ *     hipError_t; nlml_last_error() returns a thread-local message for the last failure;
+ *   - thread-safe for distinct streams; no global mutable state.
+ */
+#ifndef NLML_HPE_H
+#define NLML_HPE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NLML_ABI_VERSION 1
+
+#define NLML_E_BADARG   (-1)  /* null pointer, negative size, misaligned buffer           */
+#define NLML_E_BADBLOB  (-2)  /* packed weight blob has wrong magic / version / F         */
+#define NLML_E_SHAPE    (-3)  /* architecture other than the reference's (see pack)      */
+
+/* Fixed architecture constants of the reference model. */
+#define NLML_NUM_LANDMARKS 468   /* helpers/FeatureExtractor.py:106                      */
+#define NLML_F_REFERENCE   1404  /* configs/config_EncoderTrainer.yaml:19                */
+#define NLML_LATENT        9     /* 3 x (1,3) matrices, NLML_HPE_Model_Builder.py:187-195 */
+#define NLML_TUCKER_Q      135   /* 5*3*3*3 rows of W, TD_main.py:232-238                */
+
+int         nlml_abi_version(void);
+const char* nlml_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  IPD landmark normalisation.
+ * Replaces Read_Landmarks_and_Normalizing_using_IPD (helpers/FeatureExtractor.py:30-66) plus
+ * the f32 cast of its callers (:101,:142,:187), batched over faces.
+ *   raw      f32[B,468,3]  FaceMesh coordinates (x,y,z interleaved)
+ *   normalize != 0: out = f32( (f64(v) - f64(raw[1][c])) / ipd ),  ipd = ||raw[33]-raw[263]||
+ *                   in f64, replaced by 1e-6 when exactly 0 (:47-48); == 0: out = raw.
+ *   out      f32[B,1404]
+ *   valid    u8[B] or NULL: 0 where the OUTPUT row is all zero -- the reference's "no face"
+ *            sentinel (FeatureExtractor.py:105-106; callers skip: NLML_HPE_Test.py:257-260).
+ * Bit-exact with the reference (f64 subtract and divide, one rounding to f32).
+ */
+int nlml_normalize_ipd(const float* raw, int64_t B, int normalize,
+                       float* out, uint8_t* valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  Encoder + three heads, fused forward.
+ * Replaces CombinedAnglePredictionModel.forward (NLML_HPE_Model_Builder.py:115-126), i.e.
+ * LandmarkEncoder.forward (:55-68) and 3 x AnglePredictionNetwork.forward (:104-105), called
+ * as model(x) at NLML_HPE_Test.py:272 / generatePose_on_video.py:209.
+ *
+ * Weights are packed ONCE on the host into the kernel's MFMA fragment order:
+ *   enc_w[i]/enc_b[i], i<6 : encoder.{0,2,4,6,8,10}.{weight,bias}, weight [out,in] row-major
+ *                            with shapes (1024,F) (512,1024) (256,512) (128,256) (64,128) (9,64)
+ *   head_w[g][i]/head_b[g][i], g<3 (yaw,pitch,roll), i<5 : model.{0,2,4,6,8}.{weight,bias},
+ *                            shapes (128,3) (256,128) (128,256) (64,128) (1,64)
+ * (the state-dict layout of models/Encoder.pth and models/{yaw,pitch,roll}_network.pth).
+ * mode: NLML_MODE_F32 = f32 storage + f32 MFMA (parity mode, <=1e-4 deg of the reference);
+ *       NLML_MODE_BF16 = bf16 storage + bf16 MFMA, f32 accumulate (throughput mode; its
+ *       error is ~0.1 deg and is never claimed as parity).
+ */
+#define NLML_MODE_F32  0
+#define NLML_MODE_BF16 1
+
+size_t nlml_encoder_heads_packed_bytes(int F, int mode);
+int    nlml_encoder_heads_pack(int F, int mode,
+                               const float* const h_enc_w[6], const float* const h_enc_b[6],
+                               const float* const h_head_w[3][5], const float* const h_head_b[3][5],
+                               void* h_blob, size_t blob_bytes);
+
+/*   x       f32[B,F], row stride ldx floats (ldx >= F)
+ *   blob    device copy of the packed blob (16-byte aligned)
+ *   out     f32[B,3]  (yaw, pitch, roll) in RADIANS -- the three [B,1] outputs of the
+ *           reference side by side (rad->deg is left to the caller, Model_Builder.py:125)
+ *   latent  f32[B,9] or NULL: the encoder output before the split (:58)
+ *   valid   u8[B] or NULL: 0 where the input row is all zero -- the "no face" sentinel the
+ *           reference's callers test per face (NLML_HPE_Test.py:257-260); the pose is still
+ *           computed for such rows, as the reference's forward would.
+ */
+int nlml_encoder_heads_fwd(const float* x, int64_t ldx, int64_t B, int F,
+                           const void* blob, size_t blob_bytes,
+                           float* out, float* latent, uint8_t* valid, void* stream);
+
+/* Test hook: as nlml_encoder_heads_fwd, and also writes pre_tanh f32[B,64] = the Linear(128,64)
+ * outputs BEFORE the Tanh (Model_Builder.py:49-50).  Everything up to there is pure f32 fma, so
+ * it is compared bit for bit against the C oracle's fmaf chain (tests/test_gpu_parity.py). */
+int nlml_encoder_heads_fwd_debug(const float* x, int64_t ldx, int64_t B, int F,
+                                 const void* blob, size_t blob_bytes,
+                                 float* out, float* latent, float* pre_tanh, void* stream);
+
+/* Fused K1+K2: raw landmarks in, pose out; the normalised features never touch HBM.
+ *   raw f32[B,468,3]; valid u8[B] or NULL as in nlml_normalize_ipd. F must be 1404. */
+int nlml_landmarks_to_pose(const float* raw, int64_t B, int normalize,
+                           const void* blob, size_t blob_bytes,
+                           float* out, float* latent, uint8_t* valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3  Tucker objective, batched over face-evaluations.
+ * Replaces objective() (TD_Tester.py:31-58): f = a*cos(b*w+c)+d (:25-28) in f64 rounded to
+ * f32 (:37,40,43); x_hat = einsum('ijklm,i,j,k,l->m', W, u, f_y, f_p, f_r) in f64 (:46);
+ * err = 0.5*sum((x-x_hat)^2) (:49).
+ *   Wm         f32[135,1404]  = W.reshape(-1,1404) of outputs/features/Trained_data.npz
+ *   x          f32[N,1404]    feature rows, row stride ldx
+ *   x_index    i32[N] or NULL: evaluation n uses row x_index[n] of x (several evaluations of
+ *              one face share its row); NULL = row n
+ *   params     f64[N,8]       (w_y, w_p, w_r, u_id[5]) per evaluation (TD_Tester.py:32-33)
+ *   cos_params f64[3,3,4]     optimized_{yaw,pitch,roll}[0:3,:] rows (a,b,c,d) (TD_Inference.py:56)
+ *   err        f64[N]
+ *   x_hat      f64[N,1404] or NULL
+ */
+int nlml_tucker_objective(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,
+                          const double* params, const double* cos_params, int64_t N,
+                          double* err, double* x_hat, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLML_HPE_H */

@@ -1,0 +1,66 @@
+"""ctypes binding of libnlml_hpe_hip.so -- the C ABI declared in include/nlml_hpe.h.
+
+The library is built in-tree by ``nlml_hpe_amd/csrc/Makefile`` (``__graft_entry__.build()``)
+and loaded from next to this file.  There is NO fallback: if the library is missing or a
+symbol is absent, importing the ops raises -- the product path never routes through CPU code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnlml_hpe_hip.so")
+
+# Every symbol include/nlml_hpe.h declares: (restype, argtypes)
+_c_f32p = C.c_void_p
+SYMBOLS = {
+    "nlml_abi_version": (C.c_int, []),
+    "nlml_last_error": (C.c_char_p, []),
+    "nlml_normalize_ipd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nlml_encoder_heads_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "nlml_encoder_heads_pack": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_size_t]),
+    "nlml_encoder_heads_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nlml_encoder_heads_fwd_debug": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nlml_landmarks_to_pose": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nlml_tucker_objective": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+MODE_F32 = 0
+MODE_BF16 = 1
+
+_lib = None
+
+
+class NlmlError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NlmlError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C nlml_hpe_amd/csrc).  There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if handle.nlml_abi_version() != 1:
+            raise NlmlError("libnlml_hpe_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().nlml_last_error()
+        raise NlmlError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,83 @@
+// abi.cpp -- the extern "C" surface declared in include/nlml_hpe.h: argument checks, then the
+// launchers in the .hip files.  No allocation, no synchronisation, no global mutable state.
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/nlml_hpe.h"
+#include "abi_internal.h"
+#include "layout.h"
+
+namespace nlml {
+static thread_local char g_err[256] = "";
+int fail(int code, const char* msg) {
+  std::snprintf(g_err, sizeof g_err, "%s", msg ? msg : "unknown error");
+  return code ? code : NLML_E_BADARG;
+}
+}  // namespace nlml
+
+using namespace nlml;
+
+extern "C" {
+
+int nlml_abi_version(void) { return NLML_ABI_VERSION; }
+const char* nlml_last_error(void) { return g_err; }
+
+int nlml_normalize_ipd(const float* raw, int64_t B, int normalize, float* out, uint8_t* valid, void* stream) {
+  if (B < 0 || (B > 0 && (!raw || !out))) return fail(NLML_E_BADARG, "normalize_ipd: null buffer or negative B");
+  if ((reinterpret_cast<uintptr_t>(raw) | reinterpret_cast<uintptr_t>(out)) & 15)
+    return fail(NLML_E_BADARG, "normalize_ipd: raw/out must be 16-byte aligned");
+  return launch_normalize_ipd(raw, B, normalize, out, valid, stream);
+}
+
+size_t nlml_encoder_heads_packed_bytes(int F, int mode) {
+  if (F <= 0 || mode != NLML_MODE_F32) return 0;
+  return blob_bytes_for(F);
+}
+
+int nlml_encoder_heads_pack(int F, int mode, const float* const h_enc_w[6], const float* const h_enc_b[6],
+                            const float* const h_head_w[3][5], const float* const h_head_b[3][5], void* h_blob,
+                            size_t blob_bytes) {
+  if (mode != NLML_MODE_F32) return fail(NLML_E_BADARG, "pack: unsupported mode");
+  if (!h_enc_w || !h_enc_b || !h_head_w || !h_head_b) return fail(NLML_E_BADARG, "pack: null table");
+  return pack_f32(F, h_enc_w, h_enc_b, h_head_w, h_head_b, h_blob, blob_bytes);
+}
+
+static int check_blob_args(int64_t B, int F, const void* blob, size_t blob_bytes, const float* out) {
+  if (B < 0 || F <= 0) return fail(NLML_E_BADARG, "encoder_heads: negative B or bad F");
+  if (B > 0 && (!blob || !out)) return fail(NLML_E_BADARG, "encoder_heads: null buffer");
+  if (reinterpret_cast<uintptr_t>(blob) & 15) return fail(NLML_E_BADARG, "encoder_heads: blob must be 16-byte aligned");
+  if (blob_bytes != blob_bytes_for(F)) return fail(NLML_E_BADBLOB, "encoder_heads: blob size does not match F");
+  return 0;
+}
+
+int nlml_encoder_heads_fwd(const float* x, int64_t ldx, int64_t B, int F, const void* blob, size_t blob_bytes,
+                           float* out, float* latent, uint8_t* valid, void* stream) {
+  if (int rc = check_blob_args(B, F, blob, blob_bytes, out)) return rc;
+  if (B > 0 && (!x || ldx < F)) return fail(NLML_E_BADARG, "encoder_heads: null x or ldx < F");
+  return launch_encoder_heads_f32(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, nullptr, stream);
+}
+
+int nlml_encoder_heads_fwd_debug(const float* x, int64_t ldx, int64_t B, int F, const void* blob, size_t blob_bytes,
+                                 float* out, float* latent, float* pre_tanh, void* stream) {
+  if (int rc = check_blob_args(B, F, blob, blob_bytes, out)) return rc;
+  if (B > 0 && (!x || ldx < F)) return fail(NLML_E_BADARG, "encoder_heads: null x or ldx < F");
+  return launch_encoder_heads_f32(x, ldx, nullptr, 0, B, F, blob, out, latent, nullptr, pre_tanh, stream);
+}
+
+int nlml_landmarks_to_pose(const float* raw, int64_t B, int normalize, const void* blob, size_t blob_bytes,
+                           float* out, float* latent, uint8_t* valid, void* stream) {
+  if (int rc = check_blob_args(B, NLML_F_REFERENCE, blob, blob_bytes, out)) return rc;
+  if (B > 0 && !raw) return fail(NLML_E_BADARG, "landmarks_to_pose: null raw");
+  return launch_encoder_heads_f32(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, nullptr, stream);
+}
+
+int nlml_tucker_objective(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,
+                          const double* params, const double* cos_params, int64_t N, double* err, double* x_hat,
+                          void* stream) {
+  if (N < 0) return fail(NLML_E_BADARG, "tucker_objective: negative N");
+  if (N > 0 && (!Wm || !x || !params || !cos_params || !err)) return fail(NLML_E_BADARG, "tucker_objective: null buffer");
+  if (N > 0 && ldx < NLML_F_REFERENCE) return fail(NLML_E_BADARG, "tucker_objective: ldx < 1404");
+  return launch_tucker_objective(Wm, x, ldx, x_index, params, cos_params, N, err, x_hat, stream);
+}
+
+}  // extern "C"

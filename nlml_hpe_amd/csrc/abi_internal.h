@@ -1,0 +1,29 @@
+// abi_internal.h -- error plumbing and cross-file declarations behind include/nlml_hpe.h.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace nlml {
+
+// Records msg in the thread-local error slot and returns code (never 0).
+int fail(int code, const char* msg);
+
+// pack.cpp
+size_t blob_bytes_for(int F);
+int pack_f32(int F, const float* const enc_w[6], const float* const enc_b[6],
+             const float* const head_w[3][5], const float* const head_b[3][5],
+             void* blob, size_t blob_bytes);
+
+// encoder_heads.hip
+int launch_encoder_heads_f32(const float* x, int64_t ldx, const float* raw, int normalize,
+                             int64_t B, int F, const void* blob, float* out, float* latent,
+                             uint8_t* valid, float* pre_tanh, void* stream);
+// normalize_ipd.hip
+int launch_normalize_ipd(const float* raw, int64_t B, int normalize, float* out, uint8_t* valid,
+                         void* stream);
+// tucker_objective.hip
+int launch_tucker_objective(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,
+                            const double* params, const double* cos_params, int64_t N,
+                            double* err, double* x_hat, void* stream);
+
+}  // namespace nlml

@@ -1,0 +1,397 @@
+// encoder_heads.hip -- K2: fused LandmarkEncoder + 3 AnglePredictionNetwork heads, f32 parity mode.
+//
+// Replaces CombinedAnglePredictionModel.forward (NLML_HPE_Model_Builder.py:115-126):
+//   encoder  Linear(F,1024) ReLU Linear(1024,512) ReLU Linear(512,256) ReLU Linear(256,128) ReLU
+//            Linear(128,64) Tanh Linear(64,9)                                   (:33-53)
+//   heads    3 x [Linear(3,128) ReLU Linear(128,256) ReLU Linear(256,128) ReLU
+//                 Linear(128,64) ReLU Linear(64,1)]                             (:76-92)
+// ~21 ATen launches per call in the reference; here ONE launch, activations never leave the CU.
+//
+// Shape of the computation on CDNA4 (gfx950):
+//   * one workgroup (4 waves, one per SIMD) = one tile of 32 faces through the WHOLE network;
+//   * every layer is D[neuron][face] += W[neuron][k] * act[k][face] on v_mfma_f32_32x32x2_f32
+//     (exact f32: a k-ordered fmaf chain), neurons on MFMA rows, the 32 faces on MFMA columns;
+//   * waves split the NEURONS of a layer, so weights are private to a wave and stream
+//     global -> VGPR in the pre-packed fragment order of layout.h (one coalesced 1-KiB
+//     dwordx4 load per 32x8 weight block, L2/MALL resident, prefetched one K step ahead);
+//   * activations are shared by the 4 waves and live in LDS as [face][k] rows (stride 4*odd
+//     floats => conflict-free ds_read_b128 / ds_write_b128); each lane reads 16 B = the four
+//     k values of its face for the four MFMAs of a K step;
+//   * bias is the accumulator's initial value; ReLU/Tanh are applied on the way to LDS;
+//   * layer 0 streams x through a double-buffered 32x64 LDS slab (coalesced 256-B row reads),
+//     optionally applying the IPD normalisation (FeatureExtractor.py:30-66) in f64 on the way
+//     in, so normalised features never exist in HBM.
+#include <hip/hip_runtime.h>
+
+#include "../../include/nlml_hpe.h"
+#include "abi_internal.h"
+#include "layout.h"
+
+namespace nlml {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+
+struct EncArgs {
+  const float* x;       // [B, ldx] features, or raw landmarks [B,1404] when norm != 0
+  int64_t ldx;
+  int64_t B;
+  int F;
+  int norm;             // 1: x is raw landmarks, apply IPD normalisation while staging
+  const void* blob;
+  float* out;           // [B,3]
+  float* latent;        // [B,9] or null
+  uint8_t* valid;       // [B] or null
+  float* pre_tanh;      // [B,64] or null: E4 accumulators before the Tanh (test hook)
+};
+
+template <int ACT>
+__device__ __forceinline__ float activate(float v) {
+  if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+  if (ACT == ACT_TANH) return tanhf(v);
+  return v;
+}
+
+template <int NB>
+__device__ __forceinline__ void load_bias(f32x16 (&acc)[NB], const f32x4* __restrict__ b, int h) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const f32x4* p = b + (nb * 2 + h) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = p[q];
+      acc[nb][4 * q + 0] = v[0];
+      acc[nb][4 * q + 1] = v[1];
+      acc[nb][4 * q + 2] = v[2];
+      acc[nb][4 * q + 3] = v[3];
+    }
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void mfma_step(f32x16 (&acc)[NB], const f32x4 (&w)[NB], const f32x4 x) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[nb][j], x[j], acc[nb], 0, 0, 0);
+}
+
+// K loop with the input image resident in LDS.  `w` already points at this lane's first
+// fragment of the job, `in` at this lane's (face row, k-half) of the input image.
+template <int NB>
+__device__ __forceinline__ void kloop_lds(f32x16 (&acc)[NB], const f32x4* __restrict__ w,
+                                          const float* in, int k8) {
+  f32x4 wc[NB], wn[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) wc[nb] = w[nb * 64];
+  f32x4 xc = *reinterpret_cast<const f32x4*>(in);
+  for (int s = 0; s < k8; ++s) {
+    const f32x4* wnx = w + (size_t)(s + 1) * (NB * 64);  // one step past the job on the last
+                                                         // iteration: lands in the next job / tail pad
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) wn[nb] = wnx[nb * 64];
+    const int sn = (s + 1 < k8) ? s + 1 : s;
+    const f32x4 xn = *reinterpret_cast<const f32x4*>(in + 8 * sn);
+    mfma_step<NB>(acc, wc, xc);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) wc[nb] = wn[nb];
+    xc = xn;
+  }
+}
+
+// Accumulators -> activation -> LDS image [face][neuron]; `out` points at this lane's
+// (face row, first neuron of the job + 4*h).
+template <int NB, int ACT>
+__device__ __forceinline__ void store_lds(const f32x16 (&acc)[NB], float* out) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v;
+      v[0] = activate<ACT>(acc[nb][4 * q + 0]);
+      v[1] = activate<ACT>(acc[nb][4 * q + 1]);
+      v[2] = activate<ACT>(acc[nb][4 * q + 2]);
+      v[3] = activate<ACT>(acc[nb][4 * q + 3]);
+      *reinterpret_cast<f32x4*>(out + 32 * nb + 8 * q) = v;
+    }
+}
+
+struct Ctx {
+  const f32x4* blob4;
+  const Header* hdr;
+  float* lds;
+  int lane, f, h, wv;
+};
+
+// One job whose input is an LDS image: bias init + K loop.  Returns with acc ready.
+template <int NB>
+__device__ __forceinline__ void job_compute(const Ctx& c, int stage, int job, f32x16 (&acc)[NB],
+                                            const float* in_img, int in_stride, int in_col, int k8) {
+  load_bias<NB>(acc, c.blob4 + c.hdr->b_off[stage] + job * (NB * 8), c.h);
+  const f32x4* w = c.blob4 + c.hdr->w_off[stage] + (size_t)job * c.hdr->job_w16[stage] + c.lane;
+  kloop_lds<NB>(acc, w, in_img + c.f * in_stride + in_col + 4 * c.h, k8);
+}
+
+template <int NB, int ACT>
+__device__ __forceinline__ void job_store(const Ctx& c, const f32x16 (&acc)[NB], float* out_img,
+                                          int out_stride, int out_col) {
+  store_lds<NB, ACT>(acc, out_img + c.f * out_stride + out_col + 4 * c.h);
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage E0: x[32,F] streamed through LDS slabs of 64 columns.
+template <bool VEC4, bool NORM>
+__device__ __forceinline__ void stage_e0(const Ctx& c, const EncArgs& a, int64_t row0, int tid,
+                                         f32x16 (&acc)[8]) {
+  constexpr int NB = 8;
+  float* xs = c.lds + O_XS;
+  const int F = a.F;
+  const int k8_total = (int)c.hdr->k8_e0;
+  const int nslab = (F + 63) >> 6;
+
+  // staging role of this thread: rows srow and srow+16, columns scol..scol+3 of each slab
+  const int srow = tid >> 4, scol = (tid & 15) * 4;
+  int64_t r0 = row0 + srow, r1 = row0 + srow + 16;
+  const bool live0 = r0 < a.B, live1 = r1 < a.B;
+  r0 = live0 ? r0 : a.B - 1;
+  r1 = live1 ? r1 : a.B - 1;
+  const float* p0 = a.x + r0 * a.ldx;
+  const float* p1 = a.x + r1 * a.ldx;
+
+  // IPD normalisation constants of the two rows (FeatureExtractor.py:38-48,85-86), f64
+  double ref0[3] = {0, 0, 0}, ref1[3] = {0, 0, 0}, ipd0 = 1.0, ipd1 = 1.0;
+  if (NORM) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const float* p = rr ? p1 : p0;
+      double* ref = rr ? ref1 : ref0;
+      ref[0] = (double)p[3]; ref[1] = (double)p[4]; ref[2] = (double)p[5];       // landmark 1
+      const double dx = (double)p[99] - (double)p[789];                           // 33 vs 263
+      const double dy = (double)p[100] - (double)p[790];
+      const double dz = (double)p[101] - (double)p[791];
+      double d = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));  // == np.linalg.norm (sqrt of an fma-chained ddot)
+      if (d == 0.0) d = 1e-6;
+      if (rr) ipd1 = d; else ipd0 = d;
+    }
+  }
+
+  f32x4 s0, s1;
+  bool nz0 = false, nz1 = false;
+  auto gload = [&](int s) {
+    const int k = s * 64 + scol;
+    if (VEC4) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      s0 = (k < F) ? *reinterpret_cast<const f32x4*>(p0 + k) : z;
+      s1 = (k < F) ? *reinterpret_cast<const f32x4*>(p1 + k) : z;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s0[e] = (k + e < F) ? p0[k + e] : 0.f;
+        s1[e] = (k + e < F) ? p1[k + e] : 0.f;
+      }
+    }
+  };
+  auto lwrite = [&](int s, int buf) {
+    if (NORM) {
+      const int k = s * 64 + scol;
+      int cidx = k % 3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (k + e < F) {
+          s0[e] = (float)(((double)s0[e] - ref0[cidx]) / ipd0);
+          s1[e] = (float)(((double)s1[e] - ref1[cidx]) / ipd1);
+        }
+        cidx = (cidx == 2) ? 0 : cidx + 1;
+      }
+    }
+    nz0 |= (s0[0] != 0.f) | (s0[1] != 0.f) | (s0[2] != 0.f) | (s0[3] != 0.f);
+    nz1 |= (s1[0] != 0.f) | (s1[1] != 0.f) | (s1[2] != 0.f) | (s1[3] != 0.f);
+    float* d = xs + buf * (32 * S_XS);
+    *reinterpret_cast<f32x4*>(d + srow * S_XS + scol) = s0;
+    *reinterpret_cast<f32x4*>(d + (srow + 16) * S_XS + scol) = s1;
+  };
+
+  load_bias<NB>(acc, c.blob4 + c.hdr->b_off[ST_E0] + c.wv * (NB * 8), c.h);
+  const f32x4* w = c.blob4 + c.hdr->w_off[ST_E0] + (size_t)c.wv * c.hdr->job_w16[ST_E0] + c.lane;
+
+  gload(0);
+  lwrite(0, 0);
+  f32x4 wc[NB], wn[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) wc[nb] = w[nb * 64];
+  __syncthreads();
+
+  int ks = 0;
+  for (int s = 0; s < nslab; ++s) {
+    const bool more = s + 1 < nslab;
+    if (more) gload(s + 1);
+    const float* xrow = xs + (s & 1) * (32 * S_XS) + c.f * S_XS + 4 * c.h;
+    int nk = k8_total - ks;
+    nk = nk > 8 ? 8 : nk;
+    for (int kk = 0; kk < nk; ++kk, ++ks) {
+      const f32x4* wnx = w + (size_t)(ks + 1) * (NB * 64);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) wn[nb] = wnx[nb * 64];
+      const f32x4 xc = *reinterpret_cast<const f32x4*>(xrow + 8 * kk);
+      mfma_step<NB>(acc, wc, xc);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) wc[nb] = wn[nb];
+    }
+    if (more) lwrite(s + 1, (s + 1) & 1);
+    __syncthreads();
+  }
+
+  if (a.valid) {  // all-zero feature row == "no face" (FeatureExtractor.py:105-106)
+    const unsigned long long m0 = __ballot(nz0), m1 = __ballot(nz1);
+    if ((tid & 15) == 0) {
+      const int sh = c.lane & 48;
+      if (live0) a.valid[row0 + srow] = ((m0 >> sh) & 0xFFFFull) ? 1 : 0;
+      if (live1) a.valid[row0 + srow + 16] = ((m1 >> sh) & 0xFFFFull) ? 1 : 0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+template <bool VEC4, bool NORM>
+__global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+  const int tid = threadIdx.x;
+  Ctx c;
+  c.blob4 = reinterpret_cast<const f32x4*>(a.blob);
+  c.hdr = reinterpret_cast<const Header*>(a.blob);
+  c.lds = lds;
+  c.lane = tid & 63;
+  c.f = c.lane & 31;
+  c.h = c.lane >> 5;
+  c.wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = c.wv;
+  const int64_t row0 = (int64_t)blockIdx.x * TILE_FACES;
+
+  {  // E0: F -> 1024, ReLU.  wave wv owns neurons 256*wv .. +255
+    f32x16 acc[8];
+    stage_e0<VEC4, NORM>(c, a, row0, tid, acc);
+    job_store<8, ACT_RELU>(c, acc, lds + O_H1, S_H1, 256 * wv);
+  }
+  __syncthreads();
+  {  // E1: 1024 -> 512, ReLU.  h2 overwrites h1 => barrier between the K loop and the store
+    f32x16 acc[4];
+    job_compute<4>(c, ST_E1, wv, acc, lds + O_H1, S_H1, 0, kStages[ST_E1].k8);
+    __syncthreads();
+    job_store<4, ACT_RELU>(c, acc, lds + O_H2, S_H2, 128 * wv);
+  }
+  __syncthreads();
+  {  // E2: 512 -> 256, ReLU
+    f32x16 acc[2];
+    job_compute<2>(c, ST_E2, wv, acc, lds + O_H2, S_H2, 0, kStages[ST_E2].k8);
+    job_store<2, ACT_RELU>(c, acc, lds + O_H3, S_H3, 64 * wv);
+  }
+  __syncthreads();
+  {  // E3: 256 -> 128, ReLU
+    f32x16 acc[1];
+    job_compute<1>(c, ST_E3, wv, acc, lds + O_H3, S_H3, 0, kStages[ST_E3].k8);
+    job_store<1, ACT_RELU>(c, acc, lds + O_H4, S_H4, 32 * wv);
+  }
+  __syncthreads();
+  if (wv < 2) {  // E4: 128 -> 64, Tanh
+    f32x16 acc[1];
+    job_compute<1>(c, ST_E4, wv, acc, lds + O_H4, S_H4, 0, kStages[ST_E4].k8);
+    if (a.pre_tanh && row0 + c.f < a.B) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        a.pre_tanh[(row0 + c.f) * 64 + 32 * wv + (q & 3) + 8 * (q >> 2) + 4 * c.h] = acc[0][q];
+    }
+    job_store<1, ACT_TANH>(c, acc, lds + O_H5, S_H5, 32 * wv);
+  }
+  __syncthreads();
+  if (wv == 0) {  // E5: 64 -> 9 (latent n = 3g+c on row 8g+c, other rows exact zeros)
+    f32x16 acc[1];
+    job_compute<1>(c, ST_E5, 0, acc, lds + O_H5, S_H5, 0, kStages[ST_E5].k8);
+    job_store<1, ACT_NONE>(c, acc, lds + O_LAT, S_LAT, 0);
+  }
+  __syncthreads();
+  if (a.latent) {  // optional: the encoder output before the split (Model_Builder.py:58)
+    for (int i = tid; i < TILE_FACES * NLML_LATENT; i += 256) {
+      const int ff = i / NLML_LATENT, n = i % NLML_LATENT;
+      if (row0 + ff < a.B) a.latent[(row0 + ff) * NLML_LATENT + n] = lds[O_LAT + ff * S_LAT + 8 * (n / 3) + (n % 3)];
+    }
+  }
+  // ---- heads (yaw, pitch, roll = g 0,1,2); jobs are (head, neuron block) pairs
+#pragma unroll 1
+  for (int i = 0; i < 3; ++i) {  // H0: 3 -> 128 (K padded to 8 with zeros), ReLU
+    const int job = wv * 3 + i, g = job >> 2, nb = job & 3;
+    f32x16 acc[1];
+    job_compute<1>(c, ST_H0, job, acc, lds + O_LAT, S_LAT, 8 * g, 1);
+    job_store<1, ACT_RELU>(c, acc, lds + O_HA, S_HA, 128 * g + 32 * nb);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int i = 0; i < 3; ++i) {  // H1: 128 -> 256, ReLU
+    const int job = wv * 3 + i, g = job >> 2, p = job & 3;
+    f32x16 acc[2];
+    job_compute<2>(c, ST_H1, job, acc, lds + O_HA, S_HA, 128 * g, kStages[ST_H1].k8);
+    job_store<2, ACT_RELU>(c, acc, lds + O_HB, S_HB, 256 * g + 64 * p);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int i = 0; i < 3; ++i) {  // H2: 256 -> 128, ReLU
+    const int job = wv * 3 + i, g = job >> 2, nb = job & 3;
+    f32x16 acc[1];
+    job_compute<1>(c, ST_H2, job, acc, lds + O_HB, S_HB, 256 * g, kStages[ST_H2].k8);
+    job_store<1, ACT_RELU>(c, acc, lds + O_HC, S_HC, 128 * g + 32 * nb);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int job = wv; job < 6; job += 4) {  // H3: 128 -> 64, ReLU
+    const int g = job >> 1, nb = job & 1;
+    f32x16 acc[1];
+    job_compute<1>(c, ST_H3, job, acc, lds + O_HC, S_HC, 128 * g, kStages[ST_H3].k8);
+    job_store<1, ACT_RELU>(c, acc, lds + O_HD, S_HD, 64 * g + 32 * nb);
+  }
+  __syncthreads();
+  if (wv < 3) {  // H4: 64 -> 1; neuron on accumulator row 0 = register 0 of lanes 0..31
+    f32x16 acc[1];
+    job_compute<1>(c, ST_H4, wv, acc, lds + O_HD, S_HD, 64 * wv, kStages[ST_H4].k8);
+    if (c.h == 0 && row0 + c.f < a.B) a.out[(row0 + c.f) * 3 + wv] = acc[0][0];
+  }
+}
+
+int launch_encoder_heads_f32(const float* x, int64_t ldx, const float* raw, int normalize,
+                             int64_t B, int F, const void* blob, float* out, float* latent,
+                             uint8_t* valid, float* pre_tanh, void* stream) {
+  if (B == 0) return 0;
+  EncArgs a;
+  a.B = B;
+  a.F = F;
+  a.blob = blob;
+  a.out = out;
+  a.latent = latent;
+  a.valid = valid;
+  a.pre_tanh = pre_tanh;
+  a.norm = 0;
+  if (raw) {  // raw landmarks [B,468,3]; without normalisation they ARE the feature rows
+    a.x = raw;
+    a.ldx = NLML_F_REFERENCE;
+    a.norm = normalize ? 1 : 0;
+  } else {
+    a.x = x;
+    a.ldx = ldx;
+  }
+  const bool vec4 = (F % 4 == 0) && (a.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+  const dim3 grid((unsigned)((B + TILE_FACES - 1) / TILE_FACES)), block(256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a.norm) {
+    if (vec4) hipLaunchKernelGGL((encoder_heads_f32_kernel<true, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((encoder_heads_f32_kernel<false, true>), grid, block, 0, st, a);
+  } else {
+    if (vec4) hipLaunchKernelGGL((encoder_heads_f32_kernel<true, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((encoder_heads_f32_kernel<false, false>), grid, block, 0, st, a);
+  }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
+}  // namespace nlml

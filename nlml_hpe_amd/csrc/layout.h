@@ -1,0 +1,108 @@
+// layout.h -- shared between the host packer (pack.cpp) and the device kernels.
+//
+// Packed weight blob ("fragment order") for the fused encoder+heads kernel.
+//
+// The network (NLML_HPE_Model_Builder.py:33-53,76-92) is cut into 11 STAGES; each stage is a
+// list of JOBS; one job = NB blocks of 32 output neurons that share one input slice, computed
+// by ONE wave for all 32 faces of the tile with v_mfma_f32_32x32x2_f32:
+//
+//     D[n][face] += A[n][k] * B[k][face],   A = weights (rows), B = activations (columns)
+//
+// A wave walks K in steps of 8.  In step s lane l (r = l&31, h = l>>5) needs, for each of the
+// job's neuron blocks nb, the four weights W[32*nb + r][8s + 4h + j], j = 0..3: MFMA j of the
+// step contracts k = 8s+j (lanes 0-31) and k = 8s+4+j (lanes 32-63).  The blob stores exactly
+// those 16 bytes per lane, lane-contiguous, so every weight load is one fully coalesced
+// 1-KiB global_load_dwordx4 per (step, block):
+//
+//     wfrag[job][s][nb][lane] : float4
+//
+// and the bias in the accumulator's register order (C/D map of the 32x32 MFMA: register q of
+// lane half h is row (q&3) + 8*(q>>2) + 4*h), so the accumulators are INITIALISED with it:
+//
+//     bias[job][nb][h][q] : float, q < 16
+//
+// Blob = header (256 B) | stage 0 weights | stage 0 bias | stage 1 ... | tail pad.
+// Header words (uint32): see Header below.  All offsets are in units of 16 bytes from blob start.
+#pragma once
+#include <stdint.h>
+
+namespace nlml {
+
+constexpr uint32_t BLOB_MAGIC = 0x4E4C4D4Cu;  // "NLML"
+constexpr uint32_t BLOB_VERSION = 1;
+
+constexpr int TILE_FACES = 32;   // faces per workgroup tile = MFMA N
+constexpr int NUM_WAVES = 4;
+constexpr int NUM_STAGES = 11;   // E0..E5, H0..H4
+
+// Stage ids
+enum { ST_E0 = 0, ST_E1, ST_E2, ST_E3, ST_E4, ST_E5, ST_H0, ST_H1, ST_H2, ST_H3, ST_H4 };
+
+struct StageDesc {
+  int nb;        // neuron blocks per job (accumulators held at once)
+  int jobs;      // jobs in the stage
+  int K;         // true contraction length (E0: F, filled at run time)
+  int k8;        // K steps of 8 (ceil(K/8))
+};
+
+// Static part of the stage table (E0's K/k8 depend on F).
+//                                   nb jobs   K   k8
+constexpr StageDesc kStages[NUM_STAGES] = {
+    /*E0  F   ->1024 relu*/ {8, 4, 0, 0},
+    /*E1 1024-> 512 relu*/ {4, 4, 1024, 128},
+    /*E2  512-> 256 relu*/ {2, 4, 512, 64},
+    /*E3  256-> 128 relu*/ {1, 4, 256, 32},
+    /*E4  128->  64 tanh*/ {1, 2, 128, 16},
+    /*E5   64->   9 none*/ {1, 1, 64, 8},
+    /*H0 3x(3->128) relu*/ {1, 12, 3, 1},
+    /*H1 3x(128->256)   */ {2, 12, 128, 16},
+    /*H2 3x(256->128)   */ {1, 12, 256, 32},
+    /*H3 3x(128->64)    */ {1, 6, 128, 16},
+    /*H4 3x(64->1)  none*/ {1, 3, 64, 8},
+};
+
+struct Header {
+  uint32_t magic;
+  uint32_t version;
+  uint32_t F;          // encoder input width
+  uint32_t mode;       // NLML_MODE_*
+  uint32_t k8_e0;      // ceil(F/8)
+  uint32_t total16;    // blob size in 16-byte units (incl. tail pad)
+  uint32_t w_off[NUM_STAGES];  // weights of stage, 16-byte units
+  uint32_t b_off[NUM_STAGES];  // bias of stage, 16-byte units
+  uint32_t job_w16[NUM_STAGES];  // 16-byte units per job (weights)
+  uint32_t reserved[64 - 6 - 3 * NUM_STAGES];
+};
+static_assert(sizeof(Header) == 256, "header is 256 bytes");
+
+// LDS activation images: [32 faces][stride] f32, stride = 4*odd => conflict-free ds_read_b128
+// (16-lane groups) and ds_write_b128 (8-lane groups); see DESIGN.md "LDS images".
+constexpr int S_H1 = 1028;  // E0 out 1024
+constexpr int S_H2 = 516;   // E1 out 512
+constexpr int S_H3 = 260;   // E2 out 256
+constexpr int S_H4 = 132;   // E3 out 128
+constexpr int S_H5 = 68;    // E4 out 64 (tanh)
+constexpr int S_LAT = 36;   // E5 out: latent, head g at columns 8g..8g+2, rest exact zeros
+constexpr int S_HA = 388;   // H0 out 3 x 128
+constexpr int S_HB = 772;   // H1 out 3 x 256
+constexpr int S_HC = 388;   // H2 out 3 x 128
+constexpr int S_HD = 196;   // H3 out 3 x 64
+constexpr int S_XS = 68;    // E0 input slab: 64 columns of x (+4 pad)
+
+// LDS offsets (floats).  Lifetimes are sequential; see DESIGN.md for the overlap argument.
+constexpr int O_H1 = 0;                          // 32*1028 = 32896
+constexpr int O_XS = 32 * S_H1;                  // 2 slabs x 32*68 = 4352  -> ends 37248
+constexpr int O_H2 = 0;                          // written after E1's K loop (barrier)
+constexpr int O_H3 = 32 * S_H2;                  // 16512 .. 24832
+constexpr int O_H4 = O_H3 + 32 * S_H3;           // 24832 .. 29056
+constexpr int O_H5 = 0;                          // 2176
+constexpr int O_LAT = 32 * S_H5;                 // 2176 .. 3328
+constexpr int O_HB = 0;                          // 24704
+constexpr int O_HA = 32 * S_HB;                  // 24704 .. 37120
+constexpr int O_HC = O_HA;
+constexpr int O_HD = 0;
+constexpr int LDS_FLOATS = O_XS + 2 * 32 * S_XS;  // 37248 floats = 148992 B
+static_assert(O_HA + 32 * S_HA <= LDS_FLOATS, "LDS map");
+static_assert(O_H4 + 32 * S_H4 <= LDS_FLOATS, "LDS map");
+
+}  // namespace nlml

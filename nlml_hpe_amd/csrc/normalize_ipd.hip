@@ -1,0 +1,75 @@
+// normalize_ipd.hip -- K1: stand-alone IPD landmark normalisation (HBM-bound streaming kernel).
+//
+// Replaces Read_Landmarks_and_Normalizing_using_IPD (helpers/FeatureExtractor.py:30-66) and the
+// f32 cast of its callers (:101): out = f32((f64(v) - f64(lm[1][c])) / ipd), with
+// ipd = ||lm[33] - lm[263]||_2 in f64 (np.linalg.norm == sqrt of an fma-chained dot on the
+// reference's BLAS; reproduced explicitly below), 1e-6 when exactly 0 (:47-48).
+//
+// One wave per face: a face is 1404 f32 = 351 float4, read and written as fully coalesced
+// 16-B-per-lane accesses (6 wave-instructions each way).  Algorithmic bytes per face:
+// 5616 read + 5616 written = 11,232 B.  The f64 subtract+divide (one true IEEE division per
+// element, needed for bit-exactness) hides under the stream.
+#include <hip/hip_runtime.h>
+
+#include "../../include/nlml_hpe.h"
+#include "abi_internal.h"
+
+namespace nlml {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int F4 = NLML_F_REFERENCE / 4;  // 351 float4 per face
+
+__global__ __launch_bounds__(256) void normalize_ipd_kernel(const float* __restrict__ raw, int64_t B,
+                                                            int normalize, float* __restrict__ out,
+                                                            uint8_t* __restrict__ valid) {
+  const int lane = threadIdx.x & 63;
+  const int64_t face = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (face >= B) return;  // whole wave leaves together
+  const float* p = raw + face * NLML_F_REFERENCE;
+  float* o = out + face * NLML_F_REFERENCE;
+
+  double ref[3] = {0.0, 0.0, 0.0}, ipd = 1.0;
+  if (normalize) {
+    ref[0] = (double)p[3]; ref[1] = (double)p[4]; ref[2] = (double)p[5];    // nose tip, landmark 1
+    const double dx = (double)p[99] - (double)p[789];                        // landmark 33 - 263
+    const double dy = (double)p[100] - (double)p[790];
+    const double dz = (double)p[101] - (double)p[791];
+    ipd = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
+    if (ipd == 0.0) ipd = 1e-6;
+  }
+  bool nz = false;
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int i = it * 64 + lane;
+    if (i < F4) {
+      f32x4 v = reinterpret_cast<const f32x4*>(p)[i];
+      if (normalize) {
+        int c = (4 * i) % 3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = (float)(((double)v[e] - ref[c]) / ipd);
+          c = (c == 2) ? 0 : c + 1;
+        }
+      }
+      nz |= (v[0] != 0.f) | (v[1] != 0.f) | (v[2] != 0.f) | (v[3] != 0.f);
+      reinterpret_cast<f32x4*>(o)[i] = v;
+    }
+  }
+  if (valid) {
+    const unsigned long long m = __ballot(nz);
+    if (lane == 0) valid[face] = m ? 1 : 0;
+  }
+}
+
+int launch_normalize_ipd(const float* raw, int64_t B, int normalize, float* out, uint8_t* valid,
+                         void* stream) {
+  if (B == 0) return 0;
+  const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+  hipLaunchKernelGGL(normalize_ipd_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), raw, B,
+                     normalize, out, valid);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
+}  // namespace nlml

@@ -1,0 +1,129 @@
+// pack.cpp -- host-side packer: reference state-dict weights -> MFMA fragment-order blob.
+// Layout contract: layout.h.  Weight sources follow NLML_HPE_Model_Builder.py:33-53 (encoder)
+// and :76-92 (heads); [out,in] row-major as torch.nn.Linear stores them.
+#include <cstring>
+#include <vector>
+
+#include "../../include/nlml_hpe.h"
+#include "abi_internal.h"
+#include "layout.h"
+
+namespace nlml {
+
+namespace {
+
+struct JobSrc {
+  const float* W;   // [N][K] row-major
+  const float* b;   // [N]
+  int K;            // true K
+  int N;            // true N
+  int row0;         // first neuron of the job (for plain jobs)
+  int special;      // 0: rows row0 + i;  1: E5 latent placement;  2: H4 single row
+};
+
+// neuron index feeding accumulator row i (0 .. 32*nb-1) of the job, or -1 for a zero row
+inline int row_of(const JobSrc& j, int i) {
+  switch (j.special) {
+    case 1: {  // E5: latent n = 3g + c lands on row 8g + c  -> head g reads columns 8g..8g+7
+      int g = i >> 3, c = i & 7;
+      return (i < 24 && c < 3) ? 3 * g + c : -1;
+    }
+    case 2:  // H4: the single output neuron on row 0
+      return i == 0 ? 0 : -1;
+    default: {
+      int n = j.row0 + i;
+      return n < j.N ? n : -1;
+    }
+  }
+}
+
+}  // namespace
+
+size_t blob_bytes_for(int F) {
+  size_t units = sizeof(Header) / 16;
+  for (int s = 0; s < NUM_STAGES; ++s) {
+    const StageDesc& d = kStages[s];
+    int k8 = (s == ST_E0) ? (F + 7) / 8 : d.k8;
+    units += (size_t)d.jobs * k8 * d.nb * 64;      // weights: float4 per lane
+    units += (size_t)d.jobs * d.nb * 2 * 4;        // bias: 2 halves x 16 floats
+  }
+  units += 8 * 64 + 64;  // tail pad: the K-loop prefetches one step (<= 8 blocks) past a job's end
+  return units * 16;
+}
+
+int pack_f32(int F, const float* const enc_w[6], const float* const enc_b[6],
+             const float* const head_w[3][5], const float* const head_b[3][5],
+             void* blob, size_t blob_bytes) {
+  if (F <= 0 || !blob) return fail(NLML_E_BADARG, "pack: bad F or null blob");
+  const size_t need = blob_bytes_for(F);
+  if (blob_bytes < need) return fail(NLML_E_BADARG, "pack: blob buffer too small");
+  for (int i = 0; i < 6; ++i)
+    if (!enc_w[i] || !enc_b[i]) return fail(NLML_E_BADARG, "pack: null encoder tensor");
+  for (int g = 0; g < 3; ++g)
+    for (int i = 0; i < 5; ++i)
+      if (!head_w[g][i] || !head_b[g][i]) return fail(NLML_E_BADARG, "pack: null head tensor");
+
+  std::memset(blob, 0, blob_bytes);
+  Header* hdr = reinterpret_cast<Header*>(blob);
+  float* base = reinterpret_cast<float*>(blob);
+  hdr->magic = BLOB_MAGIC;
+  hdr->version = BLOB_VERSION;
+  hdr->F = (uint32_t)F;
+  hdr->mode = NLML_MODE_F32;
+  hdr->k8_e0 = (uint32_t)((F + 7) / 8);
+
+  const int encN[6] = {1024, 512, 256, 128, 64, 9};
+  const int encK[6] = {F, 1024, 512, 256, 128, 64};
+  const int headN[5] = {128, 256, 128, 64, 1};
+  const int headK[5] = {3, 128, 256, 128, 64};
+
+  size_t cur = sizeof(Header) / 16;  // 16-byte units
+  for (int s = 0; s < NUM_STAGES; ++s) {
+    const StageDesc& d = kStages[s];
+    const int k8 = (s == ST_E0) ? (F + 7) / 8 : d.k8;
+    const size_t job_w16 = (size_t)k8 * d.nb * 64;
+    hdr->w_off[s] = (uint32_t)cur;
+    hdr->job_w16[s] = (uint32_t)job_w16;
+    const size_t b_off = cur + (size_t)d.jobs * job_w16;
+    hdr->b_off[s] = (uint32_t)b_off;
+
+    for (int j = 0; j < d.jobs; ++j) {
+      JobSrc src{};
+      if (s <= ST_E5) {
+        src.W = enc_w[s]; src.b = enc_b[s]; src.K = encK[s]; src.N = encN[s];
+        src.row0 = j * d.nb * 32;
+        src.special = (s == ST_E5) ? 1 : 0;
+      } else {
+        const int li = s - ST_H0;
+        const int per_head = d.jobs / 3;
+        const int g = j / per_head, sub = j % per_head;
+        src.W = head_w[g][li]; src.b = head_b[g][li]; src.K = headK[li]; src.N = headN[li];
+        src.row0 = sub * d.nb * 32;
+        src.special = (s == ST_H4) ? 2 : 0;
+      }
+      float* w = base + (cur + (size_t)j * job_w16) * 4;
+      for (int st = 0; st < k8; ++st)
+        for (int nb = 0; nb < d.nb; ++nb)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int n = row_of(src, nb * 32 + (lane & 31));
+            float* dst = w + (((size_t)st * d.nb + nb) * 64 + lane) * 4;
+            for (int e = 0; e < 4; ++e) {
+              const int k = 8 * st + 4 * (lane >> 5) + e;
+              dst[e] = (n >= 0 && k < src.K) ? src.W[(size_t)n * src.K + k] : 0.0f;
+            }
+          }
+      float* b = base + (b_off + (size_t)j * d.nb * 8) * 4;
+      for (int nb = 0; nb < d.nb; ++nb)
+        for (int h = 0; h < 2; ++h)
+          for (int q = 0; q < 16; ++q) {
+            const int n = row_of(src, nb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h);
+            b[(nb * 2 + h) * 16 + q] = n >= 0 ? src.b[n] : 0.0f;
+          }
+    }
+    cur = b_off + (size_t)d.jobs * d.nb * 8;
+  }
+  hdr->total16 = (uint32_t)(need / 16);
+  return 0;
+}
+
+}  // namespace nlml

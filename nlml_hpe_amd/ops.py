@@ -1,0 +1,144 @@
+"""torch-facing operators over the C ABI (include/nlml_hpe.h).
+
+Each function takes CUDA(HIP) tensors, checks shapes/dtypes on the host (a wrong shape must
+never reach a hand-written kernel), and launches on torch's CURRENT stream.  The same entry
+points are registered as ``torch.ops.nlml_hpe.*`` custom ops.  No CPU path:
+a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+F_REF = 1404
+LATENT = 9
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(t: torch.Tensor, name: str, dtype) -> None:
+    if not t.is_cuda:
+        raise _lib.NlmlError(f"{name}: expected a GPU tensor (there is no CPU fallback), got device {t.device}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def normalize_ipd(raw: torch.Tensor, normalize: bool = True, return_valid: bool = False):
+    """raw f32[B,468,3] -> features f32[B,1404] (FeatureExtractor.py:30-66,101), bit-exact."""
+    _need_cuda(raw, "raw", torch.float32)
+    if raw.dim() != 3 or raw.shape[1:] != (468, 3):
+        raise ValueError(f"raw: expected [B,468,3], got {tuple(raw.shape)}")
+    raw = raw.contiguous()
+    B = raw.shape[0]
+    out = torch.empty((B, F_REF), dtype=torch.float32, device=raw.device)
+    valid = torch.empty((B,), dtype=torch.uint8, device=raw.device) if return_valid else None
+    _lib.check(_lib.lib().nlml_normalize_ipd(raw.data_ptr(), B, int(bool(normalize)), out.data_ptr(),
+                                             valid.data_ptr() if valid is not None else None, _stream_ptr()),
+               "nlml_normalize_ipd")
+    return (out, valid.bool()) if return_valid else out
+
+
+def encoder_heads_fwd(x: torch.Tensor, blob: torch.Tensor, F: int, return_latent: bool = False,
+                      return_valid: bool = False):
+    """x f32[B,F] -> radians f32[B,3] (CombinedAnglePredictionModel.forward, Model_Builder.py:115-126)."""
+    _need_cuda(x, "x", torch.float32)
+    _need_cuda(blob, "blob", torch.uint8)
+    if x.dim() != 2 or x.shape[1] != F:
+        raise ValueError(f"x: expected [B,{F}], got {tuple(x.shape)}")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    B = x.shape[0]
+    ldx = x.stride(0) if B > 1 else F
+    out = torch.empty((B, 3), dtype=torch.float32, device=x.device)
+    latent = torch.empty((B, LATENT), dtype=torch.float32, device=x.device) if return_latent else None
+    valid = torch.empty((B,), dtype=torch.uint8, device=x.device) if return_valid else None
+    _lib.check(_lib.lib().nlml_encoder_heads_fwd(
+        x.data_ptr(), ldx, B, F, blob.data_ptr(), blob.numel(), out.data_ptr(),
+        latent.data_ptr() if latent is not None else None,
+        valid.data_ptr() if valid is not None else None, _stream_ptr()), "nlml_encoder_heads_fwd")
+    res = [out]
+    if return_latent:
+        res.append(latent)
+    if return_valid:
+        res.append(valid.bool())
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+def encoder_heads_fwd_debug(x: torch.Tensor, blob: torch.Tensor, F: int):
+    """Test hook: (out [B,3], latent [B,9], pre_tanh [B,64]); see include/nlml_hpe.h."""
+    _need_cuda(x, "x", torch.float32)
+    _need_cuda(blob, "blob", torch.uint8)
+    if x.dim() != 2 or x.shape[1] != F:
+        raise ValueError(f"x: expected [B,{F}], got {tuple(x.shape)}")
+    x = x.contiguous()
+    B = x.shape[0]
+    out = torch.empty((B, 3), dtype=torch.float32, device=x.device)
+    latent = torch.empty((B, LATENT), dtype=torch.float32, device=x.device)
+    pre = torch.empty((B, 64), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().nlml_encoder_heads_fwd_debug(x.data_ptr(), F, B, F, blob.data_ptr(), blob.numel(),
+                                                       out.data_ptr(), latent.data_ptr(), pre.data_ptr(), _stream_ptr()),
+               "nlml_encoder_heads_fwd_debug")
+    return out, latent, pre
+
+
+def landmarks_to_pose(raw: torch.Tensor, blob: torch.Tensor, normalize: bool = True, return_latent: bool = False,
+                      return_valid: bool = False):
+    """Fused K1+K2: raw f32[B,468,3] -> radians f32[B,3]; normalised features never reach HBM."""
+    _need_cuda(raw, "raw", torch.float32)
+    _need_cuda(blob, "blob", torch.uint8)
+    if raw.dim() != 3 or raw.shape[1:] != (468, 3):
+        raise ValueError(f"raw: expected [B,468,3], got {tuple(raw.shape)}")
+    raw = raw.contiguous()
+    B = raw.shape[0]
+    out = torch.empty((B, 3), dtype=torch.float32, device=raw.device)
+    latent = torch.empty((B, LATENT), dtype=torch.float32, device=raw.device) if return_latent else None
+    valid = torch.empty((B,), dtype=torch.uint8, device=raw.device) if return_valid else None
+    _lib.check(_lib.lib().nlml_landmarks_to_pose(
+        raw.data_ptr(), B, int(bool(normalize)), blob.data_ptr(), blob.numel(), out.data_ptr(),
+        latent.data_ptr() if latent is not None else None,
+        valid.data_ptr() if valid is not None else None, _stream_ptr()), "nlml_landmarks_to_pose")
+    res = [out]
+    if return_latent:
+        res.append(latent)
+    if return_valid:
+        res.append(valid.bool())
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+def tucker_objective(Wm: torch.Tensor, x: torch.Tensor, params: torch.Tensor, cos_params: torch.Tensor,
+                     x_index: torch.Tensor | None = None, return_xhat: bool = False):
+    """Batched objective (TD_Tester.py:31-58): Wm f32[135,1404], x f32[M,1404], params f64[N,8],
+    cos_params f64[3,3,4] -> err f64[N] (+ x_hat f64[N,1404])."""
+    _need_cuda(Wm, "Wm", torch.float32)
+    _need_cuda(x, "x", torch.float32)
+    _need_cuda(params, "params", torch.float64)
+    _need_cuda(cos_params, "cos_params", torch.float64)
+    if tuple(Wm.shape) != (135, F_REF):
+        raise ValueError(f"Wm: expected [135,1404], got {tuple(Wm.shape)}")
+    if x.dim() != 2 or x.shape[1] != F_REF:
+        raise ValueError(f"x: expected [M,1404], got {tuple(x.shape)}")
+    if params.dim() != 2 or params.shape[1] != 8:
+        raise ValueError(f"params: expected [N,8], got {tuple(params.shape)}")
+    if tuple(cos_params.shape) != (3, 3, 4):
+        raise ValueError(f"cos_params: expected [3,3,4], got {tuple(cos_params.shape)}")
+    Wm, x, params, cos_params = Wm.contiguous(), x.contiguous(), params.contiguous(), cos_params.contiguous()
+    N = params.shape[0]
+    if x_index is not None:
+        _need_cuda(x_index, "x_index", torch.int32)
+        if x_index.shape != (N,):
+            raise ValueError("x_index: expected [N]")
+        x_index = x_index.contiguous()
+        if N and (int(x_index.min()) < 0 or int(x_index.max()) >= x.shape[0]):
+            raise IndexError("x_index out of range")
+    elif x.shape[0] != N:
+        raise ValueError(f"x has {x.shape[0]} rows but params has {N} (pass x_index to share rows)")
+    err = torch.empty((N,), dtype=torch.float64, device=x.device)
+    xh = torch.empty((N, F_REF), dtype=torch.float64, device=x.device) if return_xhat else None
+    _lib.check(_lib.lib().nlml_tucker_objective(
+        Wm.data_ptr(), x.data_ptr(), F_REF, x_index.data_ptr() if x_index is not None else None,
+        params.data_ptr(), cos_params.data_ptr(), N, err.data_ptr(),
+        xh.data_ptr() if xh is not None else None, _stream_ptr()), "nlml_tucker_objective")
+    return (err, xh) if return_xhat else err

@@ -1,0 +1,129 @@
+/* oracle.c -- plain-C CPU restatement of the NLML_HPE hot path.  TEST INFRASTRUCTURE ONLY
+ * (see oracle/__init__.py): loaded by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg, never by the product package.
+ *
+ * Each function cites the reference lines it follows (paths under /root/reference).
+ * Unlike the numpy oracle, summation ORDER is fixed here, and selectable to equal the order the
+ * HIP kernel's MFMA chains use, so GPU results can be compared bit for bit wherever the
+ * arithmetic is pure fma (everything up to the Tanh).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- helpers/FeatureExtractor.py:30-66 + the .float() at :101 ---------------------------- */
+void oracle_normalize_ipd(const float* raw, int64_t B, int normalize, float* out) {
+  for (int64_t b = 0; b < B; ++b) {
+    const float* p = raw + b * 1404;
+    float* o = out + b * 1404;
+    if (!normalize) { memcpy(o, p, 1404 * sizeof(float)); continue; }
+    const double ref[3] = {p[3], p[4], p[5]};                                /* landmark 1, :85-86 */
+    const double dx = (double)p[99] - (double)p[789];                        /* 33 vs 263, :38-43 */
+    const double dy = (double)p[100] - (double)p[790];
+    const double dz = (double)p[101] - (double)p[791];
+    double ipd = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));  /* np.linalg.norm == sqrt(ddot): fma chain on this BLAS */
+    if (ipd == 0.0) ipd = 1e-6;                                              /* :47-48 */
+    for (int k = 0; k < 1404; ++k) o[k] = (float)(((double)p[k] - ref[k % 3]) / ipd);   /* :55-61 */
+  }
+}
+
+/* One Linear layer for one row.  order 0: k ascending; order 1: the HIP kernel's MFMA chain
+ * order -- within each group of 8: k, k+4, k+1, k+5, k+2, k+6, k+3, k+7 (layout.h). */
+static void linear_row(const float* x, const float* W, const float* b, int K, int N, float* y, int order) {
+  for (int n = 0; n < N; ++n) {
+    const float* w = W + (size_t)n * K;
+    float acc = b[n];
+    if (order == 0) {
+      for (int k = 0; k < K; ++k) acc = fmaf(w[k], x[k], acc);
+    } else {
+      int k0 = 0;
+      for (; k0 + 8 <= K; k0 += 8)
+        for (int j = 0; j < 4; ++j) {
+          acc = fmaf(w[k0 + j], x[k0 + j], acc);
+          acc = fmaf(w[k0 + 4 + j], x[k0 + 4 + j], acc);
+        }
+      if (k0 < K) /* zero-padded tail step: padded products are exact zeros and change nothing */
+        for (int j = 0; j < 4; ++j) {
+          if (k0 + j < K) acc = fmaf(w[k0 + j], x[k0 + j], acc);
+          if (k0 + 4 + j < K) acc = fmaf(w[k0 + 4 + j], x[k0 + 4 + j], acc);
+        }
+    }
+    y[n] = acc;
+  }
+}
+
+/* ---- NLML_HPE_Model_Builder.py:55-68 (encoder), :104-105 (heads), :115-126 (combined) -----
+ * enc_w[i] [out,in] for widths F->1024->512->256->128->64->9; head_w[3*5] in (yaw,pitch,roll) x
+ * layer order with widths 3->128->256->128->64->1.  out [B,3] radians; latent [B,9] and
+ * pre_tanh [B,64] optional (NULL to skip). */
+void oracle_encoder_heads_f32(const float* x, int64_t B, int F, const float* const* enc_w,
+                              const float* const* enc_b, const float* const* head_w,
+                              const float* const* head_b, int order, float* out, float* latent,
+                              float* pre_tanh) {
+  static const int EN[7] = {0, 1024, 512, 256, 128, 64, 9};
+  static const int HN[6] = {3, 128, 256, 128, 64, 1};
+#pragma omp parallel
+  {
+    float* a = (float*)malloc(sizeof(float) * (F > 1024 ? F : 1024));
+    float* c = (float*)malloc(sizeof(float) * 1024);
+#pragma omp for schedule(static)
+    for (int64_t r = 0; r < B; ++r) {
+      memcpy(a, x + r * F, sizeof(float) * F);
+      int K = F;
+      for (int l = 0; l < 6; ++l) {
+        const int N = EN[l + 1];
+        linear_row(a, enc_w[l], enc_b[l], K, N, c, order);
+        if (l == 4 && pre_tanh) memcpy(pre_tanh + r * 64, c, sizeof(float) * 64);
+        for (int n = 0; n < N; ++n)
+          a[n] = (l < 4) ? fmaxf(c[n], 0.0f) : (l == 4 ? tanhf(c[n]) : c[n]);   /* ReLU x4, Tanh, none */
+        K = N;
+      }
+      float lat[9];
+      memcpy(lat, a, sizeof lat);
+      if (latent) memcpy(latent + r * 9, lat, sizeof lat);
+      for (int g = 0; g < 3; ++g) {                          /* latent[:, 3g:3g+3] -> head g, :118-124 */
+        memcpy(a, lat + 3 * g, 3 * sizeof(float));
+        int Kh = 3;
+        for (int l = 0; l < 5; ++l) {
+          const int N = HN[l + 1];
+          linear_row(a, head_w[g * 5 + l], head_b[g * 5 + l], Kh, N, c, order);
+          for (int n = 0; n < N; ++n) a[n] = (l < 4) ? fmaxf(c[n], 0.0f) : c[n];
+          Kh = N;
+        }
+        out[r * 3 + g] = a[0];
+      }
+    }
+    free(a);
+    free(c);
+  }
+}
+
+/* ---- TD_Tester.py:25-28 (func), :31-58 (objective) ---------------------------------------
+ * Wm f32[135,1404]; x f32[N,1404]; params f64[N,8]; cosp f64[3,3,4]; err f64[N]; xhat f64[N,1404]|NULL.
+ * x_hat[m] = sum_q c[q]*Wm[q][m], q ascending in one fma chain (the HIP kernel's order). */
+void oracle_tucker_objective(const float* Wm, const float* x, const double* params, const double* cosp,
+                             int64_t N, double* err, double* xhat) {
+#pragma omp parallel for schedule(static)
+  for (int64_t n = 0; n < N; ++n) {
+    const double* p = params + n * 8;
+    double f[3][3];
+    for (int a = 0; a < 3; ++a)
+      for (int j = 0; j < 3; ++j) {
+        const double* cp = cosp + (a * 3 + j) * 4;
+        f[a][j] = (double)(float)(cp[0] * cos(cp[1] * p[a] + cp[2]) + cp[3]);   /* :26, .astype(f32) :37 */
+      }
+    double c[135];
+    for (int q = 0; q < 135; ++q)
+      c[q] = ((p[3 + q / 27] * f[0][(q / 9) % 3]) * f[1][(q / 3) % 3]) * f[2][q % 3];
+    double s = 0.0;
+    for (int m = 0; m < 1404; ++m) {
+      double acc = 0.0;
+      for (int q = 0; q < 135; ++q) acc = fma(c[q], (double)Wm[(size_t)q * 1404 + m], acc);
+      if (xhat) xhat[n * 1404 + m] = acc;
+      const double r = (double)x[n * 1404 + m] - acc;
+      s += r * r;
+    }
+    err[n] = 0.5 * s;                                                           /* :49 */
+  }
+}

@@ -1,0 +1,187 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle and the golden
+fixtures.  Tolerances: pose 1e-4 degrees absolute (BASELINE.json north_star); normalisation and
+validity bit-exact; Tucker objective 1e-12 relative (f64)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from nlml_hpe_amd import ops, synth, weights
+from oracle import encoder_heads as EH
+from oracle import feature_norm as FN
+from oracle import tucker as TK
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_DEG = 1e-4
+
+
+def _report(name, **kv):
+    """Append measured margins to gpurun_out/parity_margins.jsonl (read back after the GPU call)."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_margins.jsonl"), "a") as f:
+            f.write(json.dumps({"test": name, **{k: float(v) for k, v in kv.items()}}) + "\n")
+    except OSError:
+        pass
+
+
+def _blob(sd, head_sds, device):
+    return torch.from_numpy(weights.pack_blob(sd, head_sds)).to(device)
+
+
+@pytest.mark.parametrize("F", [1404, 136])
+def test_fx3_encoder_heads_golden(F, head_sds, golden_dir, device):
+    g = np.load(os.path.join(golden_dir, "fx3_encoder_heads.npz"))
+    sd = synth.encoder_state_dict(F, seed=0)
+    x = synth.features(256, F, seed=1)
+    x[7] = 0.0
+    assert float(x.astype(np.float64).sum()) == g[f"x_crc_F{F}"][0]
+    out, valid = ops.encoder_heads_fwd(torch.from_numpy(x).to(device), _blob(sd, head_sds, device), F, return_valid=True)
+    out = out.cpu().numpy()
+    err = np.degrees(np.abs(out - g[f"rad_F{F}"]).max())
+    _report(f"fx3_golden_F{F}", max_abs_deg=err)
+    assert err <= POSE_TOL_DEG, err
+    v = valid.cpu().numpy()
+    assert not v[7] and v.sum() == 255
+
+
+@pytest.mark.parametrize("F,B", [(1404, 1), (1404, 31), (1404, 33), (1404, 1000), (136, 77), (64, 50), (10, 40), (1407, 65)])
+def test_encoder_heads_vs_oracle(F, B, head_sds, device):
+    sd = synth.encoder_state_dict(F, seed=3)
+    x = synth.features(B, F, seed=9)
+    P = EH.Params(sd, head_sds)
+    ref64 = EH.forward_numpy(x, P, np.float64)          # arithmetic truth
+    ref32 = EH.forward_numpy(x, P, np.float32)          # what an f32 CPU path (the reference's) gives
+    lat64 = EH.encoder_latent_numpy(x, P, np.float64)
+    out, lat = ops.encoder_heads_fwd(torch.from_numpy(x).to(device), _blob(sd, head_sds, device), F, return_latent=True)
+    out = out.cpu().numpy()
+    e64 = np.degrees(np.abs(out - ref64).max())
+    e32 = np.degrees(np.abs(out - ref32).max())
+    _report(f"vs_oracle_F{F}_B{B}", hip_vs_f64_deg=e64, hip_vs_f32_deg=e32,
+            cpu32_vs_f64_deg=np.degrees(np.abs(ref32 - ref64).max()))
+    assert e64 <= POSE_TOL_DEG and e32 <= POSE_TOL_DEG
+    assert np.abs(lat.cpu().numpy() - lat64).max() <= 2e-6
+
+
+def test_encoder_heads_strided_input(head_sds, device):
+    F = 136
+    sd = synth.encoder_state_dict(F, seed=0)
+    xfull = synth.features(100, 200, seed=4)
+    xt = torch.from_numpy(xfull).to(device)[:, 8:8 + F]          # row stride 200, offset 32 B
+    P = EH.Params(sd, head_sds)
+    ref = EH.forward_numpy(xfull[:, 8:8 + F], P, np.float64)
+    out = ops.encoder_heads_fwd(xt, _blob(sd, head_sds, device), F)
+    assert np.degrees(np.abs(out.cpu().numpy() - ref).max()) <= POSE_TOL_DEG
+
+
+def test_fx1_normalise_golden_bitexact(golden_dir, device):
+    g = np.load(os.path.join(golden_dir, "fx1_normalise.npz"))
+    raw = torch.from_numpy(g["landmarks"]).to(device)
+    out, valid = ops.normalize_ipd(raw, True, return_valid=True)
+    assert np.array_equal(out.cpu().numpy(), g["features_norm"])
+    assert valid.all()
+    out0 = ops.normalize_ipd(raw, False)
+    assert np.array_equal(out0.cpu().numpy(), g["features_raw"])
+
+
+def test_normalise_vs_oracle_bitexact_and_no_face(device):
+    raw = synth.raw_landmarks(1003, seed=21)
+    raw[5] = 0.0                      # all-zero landmarks: (0-0)/1e-6 = 0 -> "no face" row
+    raw[17, 263] = raw[17, 33]        # ipd == 0 on a non-zero face
+    ref = FN.normalize_ipd(raw, True)
+    out, valid = ops.normalize_ipd(torch.from_numpy(raw).to(device), True, return_valid=True)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    assert np.array_equal(valid.cpu().numpy(), ~FN.no_face_mask(ref))
+
+
+def test_fused_landmarks_to_pose(head_sds, device):
+    sd = synth.encoder_state_dict(1404, seed=0)
+    blob = _blob(sd, head_sds, device)
+    raw = synth.raw_landmarks(333, seed=5)
+    raw[11] = 0.0
+    rt = torch.from_numpy(raw).to(device)
+    feats = ops.normalize_ipd(rt, True)
+    two_step = ops.encoder_heads_fwd(feats, blob, 1404)
+    fused, valid = ops.landmarks_to_pose(rt, blob, True, return_valid=True)
+    assert torch.equal(fused, two_step)                     # same arithmetic, same order => same bits
+    assert not bool(valid[11]) and int(valid.sum()) == 332
+    P = EH.Params(sd, head_sds)
+    ref = EH.forward_numpy(FN.normalize_ipd(raw, True), P, np.float64)
+    assert np.degrees(np.abs(fused.cpu().numpy() - ref).max()) <= POSE_TOL_DEG
+    raw_mode = ops.landmarks_to_pose(rt, blob, False)
+    assert torch.equal(raw_mode, ops.encoder_heads_fwd(rt.reshape(333, 1404), blob, 1404))
+
+
+def test_determinism(head_sds, device):
+    sd = synth.encoder_state_dict(1404, seed=0)
+    blob = _blob(sd, head_sds, device)
+    x = torch.from_numpy(synth.features(4096, 1404, seed=2)).to(device)
+    a = ops.encoder_heads_fwd(x, blob, 1404)
+    b = ops.encoder_heads_fwd(x, blob, 1404)
+    assert torch.equal(a, b)
+
+
+def _cos_params(art):
+    return np.stack([art["optimized_yaw"][0:3], art["optimized_pitch"][0:3], art["optimized_roll"][0:3]])
+
+
+def test_fx4_tucker_objective_golden(tucker_art, golden_dir, device):
+    g = np.load(os.path.join(golden_dir, "fx4_td_objective.npz"))
+    Wm = torch.from_numpy(tucker_art["W"].reshape(135, 1404)).to(device)
+    err, xh = ops.tucker_objective(Wm, torch.from_numpy(g["x"]).to(device), torch.from_numpy(g["params"]).to(device),
+                                   torch.from_numpy(_cos_params(tucker_art)).to(device), return_xhat=True)
+    err = err.cpu().numpy()
+    assert np.max(np.abs(err - g["err"]) / np.abs(g["err"])) <= 1e-12
+    xh = xh.cpu().numpy()[:8]
+    assert np.max(np.abs(xh - g["x_hat"])) <= 1e-12 * np.max(np.abs(g["x_hat"]))
+
+
+def test_tucker_objective_shared_rows_and_ragged(tucker_art, device):
+    N = 1001                                  # not a multiple of the 8 evaluations per workgroup
+    P = synth.tucker_params(N, 5, seed=6)
+    X = synth.features(7, 1404, seed=6)
+    idx = (np.arange(N) % 7).astype(np.int32)
+    cp = _cos_params(tucker_art)
+    ref = TK.objective_batch(P, tucker_art["W"], X[idx], cp[0], cp[1], cp[2])
+    Wm = torch.from_numpy(tucker_art["W"].reshape(135, 1404)).to(device)
+    err = ops.tucker_objective(Wm, torch.from_numpy(X).to(device), torch.from_numpy(P).to(device),
+                               torch.from_numpy(cp).to(device), x_index=torch.from_numpy(idx).to(device))
+    assert np.max(np.abs(err.cpu().numpy() - ref) / np.abs(ref)) <= 1e-12
+
+
+def test_errors_are_loud(head_sds, device):
+    from nlml_hpe_amd import _lib
+    sd = synth.encoder_state_dict(136, seed=0)
+    blob = _blob(sd, head_sds, device)
+    with pytest.raises(ValueError):
+        ops.encoder_heads_fwd(torch.zeros(4, 135, device=device), blob, 136)
+    with pytest.raises(_lib.NlmlError):
+        ops.encoder_heads_fwd(torch.zeros(4, 136), blob, 136)          # CPU tensor: no fallback
+    with pytest.raises(_lib.NlmlError):
+        ops.encoder_heads_fwd(torch.zeros(4, 1404, device=device), blob, 1404)   # blob packed for another F
+    assert ops.encoder_heads_fwd(torch.zeros(0, 136, device=device), blob, 136).shape == (0, 3)
+
+
+@pytest.mark.parametrize("F,B,gain", [(1404, 257, 1.0), (1404, 64, 2.4), (136, 100, 2.4), (10, 33, 2.4)])
+def test_mfma_chain_bitexact_vs_c_oracle(F, B, gain, head_sds, device):
+    """Everything before the Tanh is pure f32 fma: the MFMA chains must equal the C oracle's
+    fmaf chains (same k order) bit for bit, whatever the weight gain.  After the Tanh (ocml vs
+    glibc tanhf, <= 2 ulp apart) agreement stays far inside the pose tolerance."""
+    from oracle import c_oracle as CO
+    sd = synth.encoder_state_dict(F, seed=5)
+    for k in sd:
+        if k.endswith("weight"):
+            sd[k] = (sd[k] * np.float32(gain)).astype(np.float32)     # ~variance-preserving at 2.4
+    x = synth.features(B, F, seed=13)
+    P = EH.Params(sd, head_sds)
+    c_out, c_lat, c_pre = CO.encoder_heads(x, P, order=1, want_latent=True, want_pre_tanh=True)
+    out, lat, pre = ops.encoder_heads_fwd_debug(torch.from_numpy(x).to(device), _blob(sd, head_sds, device), F)
+    assert np.array_equal(pre.cpu().numpy(), c_pre)
+    _report(f"c_oracle_F{F}_gain{gain}", latent_abs=np.abs(lat.cpu().numpy() - c_lat).max(),
+            out_abs_deg=np.degrees(np.abs(out.cpu().numpy() - c_out).max()))
+    assert np.abs(lat.cpu().numpy() - c_lat).max() <= 1e-6
+    assert np.degrees(np.abs(out.cpu().numpy() - c_out).max()) <= POSE_TOL_DEG
