@@ -175,15 +175,35 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(raw_np, sd, heads, seconds):
     """The oracle ("port": same ATen ops as the reference's CPU path) on this host's cores."""
     from oracle import encoder_heads as EH
     from oracle import feature_norm as FN
-    ncores = os.cpu_count() or 1
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    ncores = usable_cores()
     torch.set_num_threads(ncores)
     P = EH.Params(sd, heads)
     n = 16384

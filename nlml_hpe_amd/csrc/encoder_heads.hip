@@ -79,26 +79,43 @@ __device__ __forceinline__ void mfma_step(f32x16 (&acc)[NB], const f32x4 (&w)[NB
       acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[nb][j], x[j], acc[nb], 0, 0, 0);
 }
 
+// Prefetch ring.  The compiler, left alone, sinks the weight loads of step s+1 below the MFMAs of
+// step s and then waits for them at once (34 % of wave cycles parked in s_waitcnt, profiles/r01):
+// so the loop is unrolled over a ring of R register buffers with the loads of step s+D (D = R-1)
+// pinned ABOVE the MFMAs of step s by sched_barrier.  R is chosen per NB so that D steps of MFMA
+// work (NB*256 cycles each) cover an L2/MALL round trip: NB 8 -> R 2, NB 4 -> R 4, NB <= 2 -> R 8.
+template <int NB> struct Ring { static constexpr int R = NB >= 8 ? 2 : (NB >= 4 ? 4 : 8); };
+
 // K loop with the input image resident in LDS.  `w` already points at this lane's first
-// fragment of the job, `in` at this lane's (face row, k-half) of the input image.
+// fragment of the job, `in` at this lane's (face row, k-half) of the input image.  Loads run up to
+// D steps past the job's end (next job / tail pad of the blob: harmless); LDS reads are clamped.
 template <int NB>
 __device__ __forceinline__ void kloop_lds(f32x16 (&acc)[NB], const f32x4* __restrict__ w,
                                           const float* in, int k8) {
-  f32x4 wc[NB], wn[NB];
+  constexpr int R = Ring<NB>::R, D = R - 1;
+  f32x4 wr[R][NB];
+  f32x4 xr[R];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) wc[nb] = w[nb * 64];
-  f32x4 xc = *reinterpret_cast<const f32x4*>(in);
-  for (int s = 0; s < k8; ++s) {
-    const f32x4* wnx = w + (size_t)(s + 1) * (NB * 64);  // one step past the job on the last
-                                                         // iteration: lands in the next job / tail pad
+  for (int d = 0; d < D; ++d) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) wn[nb] = wnx[nb * 64];
-    const int sn = (s + 1 < k8) ? s + 1 : s;
-    const f32x4 xn = *reinterpret_cast<const f32x4*>(in + 8 * sn);
-    mfma_step<NB>(acc, wc, xc);
+    for (int nb = 0; nb < NB; ++nb) wr[d][nb] = w[(d * NB + nb) * 64];
+    xr[d] = *reinterpret_cast<const f32x4*>(in + 8 * (d < k8 ? d : k8 - 1));
+  }
+  for (int s0 = 0; s0 < k8; s0 += R) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) wc[nb] = wn[nb];
-    xc = xn;
+    for (int r = 0; r < R; ++r) {
+      const int s = s0 + r;
+      if (s < k8) {
+        const int sp = s + D;
+        const f32x4* wp = w + (size_t)sp * (NB * 64);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) wr[(r + D) % R][nb] = wp[nb * 64];
+        xr[(r + D) % R] = *reinterpret_cast<const f32x4*>(in + 8 * (sp < k8 ? sp : k8 - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step<NB>(acc, wr[r], xr[r]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
 }
 
@@ -219,9 +236,11 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const EncArgs& a, int64_t
 
   gload(0);
   lwrite(0, 0);
-  f32x4 wc[NB], wn[NB];
+  // weight ring of 2 (even K steps in slot 0, odd in slot 1; a slab holds 8 steps, so the parity is
+  // static inside the unrolled slab body) and an x ring of 2 inside the slab
+  f32x4 w0[NB], w1[NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) wc[nb] = w[nb * 64];
+  for (int nb = 0; nb < NB; ++nb) w0[nb] = w[nb * 64];
   __syncthreads();
 
   int ks = 0;
@@ -231,15 +250,34 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const EncArgs& a, int64_t
     const float* xrow = xs + (s & 1) * (32 * S_XS) + c.f * S_XS + 4 * c.h;
     int nk = k8_total - ks;
     nk = nk > 8 ? 8 : nk;
-    for (int kk = 0; kk < nk; ++kk, ++ks) {
-      const f32x4* wnx = w + (size_t)(ks + 1) * (NB * 64);
+    f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow), x1;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) wn[nb] = wnx[nb * 64];
-      const f32x4 xc = *reinterpret_cast<const f32x4*>(xrow + 8 * kk);
-      mfma_step<NB>(acc, wc, xc);
+    for (int kk = 0; kk < 8; kk += 2) {
+      if (kk < nk) {
+        const f32x4* wp = w + (size_t)(ks + kk + 1) * (NB * 64);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) wc[nb] = wn[nb];
+        for (int nb = 0; nb < NB; ++nb) w1[nb] = wp[nb * 64];
+        x1 = *reinterpret_cast<const f32x4*>(xrow + 8 * (kk + 1 < nk ? kk + 1 : kk));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step<NB>(acc, w0, x0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kk + 1 < nk) {
+        const f32x4* wp = w + (size_t)(ks + kk + 2) * (NB * 64);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) w0[nb] = wp[nb * 64];
+        x0 = *reinterpret_cast<const f32x4*>(xrow + 8 * (kk + 2 < nk ? kk + 2 : kk + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step<NB>(acc, w1, x1);
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (kk < nk) {
+        // odd step count in this (last) slab: the next step's weights sit in slot 1; keep the
+        // invariant "next step is in w0" for a following slab (there is none after a partial slab)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) w0[nb] = w1[nb];
+      }
     }
+    ks += nk;
     if (more) lwrite(s + 1, (s + 1) & 1);
     __syncthreads();
   }

@@ -47,7 +47,7 @@ size_t blob_bytes_for(int F) {
     units += (size_t)d.jobs * k8 * d.nb * 64;      // weights: float4 per lane
     units += (size_t)d.jobs * d.nb * 2 * 4;        // bias: 2 halves x 16 floats
   }
-  units += 8 * 64 + 64;  // tail pad: the K-loop prefetches one step (<= 8 blocks) past a job's end
+  units += 4096;  // 64 KiB tail pad: the K loops prefetch up to 7 steps (<= 8 KiB) past a job's end
   return units * 16;
 }
 
