@@ -1,0 +1,84 @@
+"""Drop-in callable for the reference's scripted model.
+
+The reference obtains its model with
+    model = torch.jit.load("models/combined_model_scripted.pth", map_location=device); model.to(device); model.eval()
+(NLML_HPE_Test.py:217-219, generatePose_on_video.py:289-290) and calls ``model(x)`` with x f32[B,1404]
+under no_grad, getting three [B,1] tensors in RADIANS (NLML_HPE_Model_Builder.py:115-126).
+``load_model`` returns an object with the same call contract whose forward is ONE fused HIP launch.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import _lib, ops, weights
+
+
+class HIPPoseModel:
+    """CombinedAnglePredictionModel (Model_Builder.py:107-126) on the fused gfx950 kernel."""
+
+    def __init__(self, encoder_sd: dict, head_sds: dict, device="cuda", mode: int = _lib.MODE_F32):
+        self.input_size = weights.validate_shapes(encoder_sd, head_sds)
+        self.mode = mode
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.NlmlError("HIPPoseModel runs on the GPU only; there is no CPU fallback")
+        self._blob_host = torch.from_numpy(weights.pack_blob(encoder_sd, head_sds, mode))
+        self.blob = self._blob_host.to(self.device)
+
+    # -- nn.Module-shaped surface the reference's entry points touch -------------------------
+    def eval(self):
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.NlmlError("HIPPoseModel runs on the GPU only; there is no CPU fallback")
+        if device != self.device:
+            self.device = device
+            self.blob = self._blob_host.to(device)
+        return self
+
+    def __call__(self, x: torch.Tensor):
+        """x f32[B,F] (or [F]) -> (yaw[B,1], pitch[B,1], roll[B,1]) radians, like the scripted model."""
+        out = self.forward_packed(x)
+        return out[:, 0:1], out[:, 1:2], out[:, 2:3]
+
+    forward = __call__
+
+    # -- batched surface this build adds ------------------------------------------------------
+    def forward_packed(self, x: torch.Tensor, return_latent: bool = False, return_valid: bool = False):
+        """x f32[B,F] -> f32[B,3] radians (+ latent [B,9], + valid mask: row not all-zero)."""
+        if x.dim() == 1:
+            x = x.unsqueeze(0)
+        return ops.encoder_heads_fwd(x.to(self.device, torch.float32), self.blob, self.input_size,
+                                     return_latent=return_latent, return_valid=return_valid)
+
+    def from_landmarks(self, raw: torch.Tensor, normalize: bool = True, return_latent: bool = False,
+                       return_valid: bool = False):
+        """raw FaceMesh landmarks f32[B,468,3] -> f32[B,3] radians, normalisation fused into the launch."""
+        if self.input_size != ops.F_REF:
+            raise ValueError("from_landmarks needs the reference input width 1404")
+        return ops.landmarks_to_pose(raw.to(self.device, torch.float32), self.blob, normalize,
+                                     return_latent=return_latent, return_valid=return_valid)
+
+
+def load_model(path_or_dir: str = "models", device=None, encoder_state_dict: dict | None = None,
+               mode: int = _lib.MODE_F32) -> HIPPoseModel:
+    """Build the HIP model from the reference's artefact layout.
+
+    path_or_dir: a TorchScript file saved by NLML_HPE_Model_Builder.py (:222-223), or a directory holding
+    Encoder.pth and {yaw,pitch,roll}_network.pth.  The reference checkout ships no Encoder.pth; pass
+    ``encoder_state_dict`` (keys encoder.N.weight/bias) to supply encoder weights explicitly.
+    """
+    device = torch.device(device if device is not None else "cuda")
+    if os.path.isfile(path_or_dir):
+        scripted = torch.jit.load(path_or_dir, map_location="cpu")
+        enc, heads = weights.split_scripted_state_dict(scripted.state_dict())
+        if encoder_state_dict is not None:
+            enc = encoder_state_dict
+    else:
+        heads = weights.load_head_state_dicts(path_or_dir)
+        enc = encoder_state_dict if encoder_state_dict is not None else weights.load_encoder_state_dict(path_or_dir)
+    return HIPPoseModel(enc, heads, device=device, mode=mode)

@@ -142,3 +142,50 @@ def tucker_objective(Wm: torch.Tensor, x: torch.Tensor, params: torch.Tensor, co
         params.data_ptr(), cos_params.data_ptr(), N, err.data_ptr(),
         xh.data_ptr() if xh is not None else None, _stream_ptr()), "nlml_tucker_objective")
     return (err, xh) if return_xhat else err
+
+
+# ---------------------------------------------------------------------------------------------
+# torch.ops.nlml_hpe.* registration (SURVEY.md 8b "Underlying op").  The custom ops are thin
+# schemas over the functions above, so the HIP path is reachable from TorchScript-style call
+# sites (torch.ops.nlml_hpe.encoder_heads_fwd(x, blob, F)) as well as from Python.
+def _register_custom_ops():
+    lib = torch.library
+
+    @lib.custom_op("nlml_hpe::normalize_ipd", mutates_args=())
+    def _normalize_ipd(raw: torch.Tensor, normalize: bool) -> torch.Tensor:
+        return normalize_ipd(raw, normalize)
+
+    @_normalize_ipd.register_fake
+    def _(raw, normalize):
+        return raw.new_empty((raw.shape[0], F_REF))
+
+    @lib.custom_op("nlml_hpe::encoder_heads_fwd", mutates_args=())
+    def _encoder_heads_fwd(x: torch.Tensor, packed_w: torch.Tensor, F: int) -> torch.Tensor:
+        return encoder_heads_fwd(x, packed_w, F)
+
+    @_encoder_heads_fwd.register_fake
+    def _(x, packed_w, F):
+        return x.new_empty((x.shape[0], 3))
+
+    @lib.custom_op("nlml_hpe::landmarks_to_pose", mutates_args=())
+    def _landmarks_to_pose(raw: torch.Tensor, packed_w: torch.Tensor, normalize: bool) -> torch.Tensor:
+        return landmarks_to_pose(raw, packed_w, normalize)
+
+    @_landmarks_to_pose.register_fake
+    def _(raw, packed_w, normalize):
+        return raw.new_empty((raw.shape[0], 3))
+
+    @lib.custom_op("nlml_hpe::tucker_objective", mutates_args=())
+    def _tucker_objective(Wm: torch.Tensor, x: torch.Tensor, params: torch.Tensor, cos_params: torch.Tensor) -> torch.Tensor:
+        return tucker_objective(Wm, x, params, cos_params)
+
+    @_tucker_objective.register_fake
+    def _(Wm, x, params, cos_params):
+        return params.new_empty((params.shape[0],))
+
+
+try:
+    _register_custom_ops()
+except Exception as _e:  # pragma: no cover - registration is a convenience; the functions above are the API
+    import warnings
+    warnings.warn(f"torch.ops.nlml_hpe registration skipped: {_e}")

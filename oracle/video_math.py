@@ -35,8 +35,9 @@ def axes_on_face(prev_tdx, prev_tdy, frame_w, frame_h, nose, left_eye, right_eye
     pitch = pitch * np.pi / 180
     yaw = -(yaw * np.pi / 180)
     roll = roll * np.pi / 180
-    new_tdx = (nose[0] + left_eye[0] + right_eye[0]) * frame_w / 3     # :91
-    new_tdy = (nose[1] + left_eye[1] + right_eye[1]) * frame_h / 3
+    # landmark coordinates are f32 values read as Python floats: the sums run in f64 (:91-92)
+    new_tdx = (float(nose[0]) + float(left_eye[0]) + float(right_eye[0])) * frame_w / 3
+    new_tdy = (float(nose[1]) + float(left_eye[1]) + float(right_eye[1])) * frame_h / 3
     if prev_tdx is None or prev_tdy is None:
         tdx, tdy = new_tdx, new_tdy
     else:

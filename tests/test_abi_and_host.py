@@ -1,0 +1,109 @@
+"""CPU: the C-ABI library loads and exports every symbol include/nlml_hpe.h declares; the host-side
+packer, loaders and sharding logic (no GPU compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import blob_emulator as BE
+from nlml_hpe_amd import _lib, synth, weights
+from nlml_hpe_amd.distributed import shard_bounds
+from oracle import encoder_heads as EH
+
+
+def _declared_symbols(repo_root):
+    txt = open(os.path.join(repo_root, "include", "nlml_hpe.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nlml_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(repo_root):
+    names = _declared_symbols(repo_root)
+    assert len(names) >= 8
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/nlml_hpe.h but not exported"
+    assert set(names) == set(_lib.SYMBOLS), "ctypes table and header disagree"
+    assert _lib.lib().nlml_abi_version() == 1
+
+
+@pytest.mark.parametrize("F", [1404, 136, 13])
+def test_packed_blob_walk_matches_oracle(F, head_sds):
+    """Decode the blob with the kernel's index arithmetic (tests/blob_emulator.py) and compare with the oracle."""
+    sd = synth.encoder_state_dict(F, seed=0)
+    blob = weights.pack_blob(sd, head_sds)
+    assert blob.nbytes == _lib.lib().nlml_encoder_heads_packed_bytes(F, 0)
+    x = synth.features(32, F, seed=5)
+    out, lat = BE.forward(blob, x)
+    P = EH.Params(sd, head_sds)
+    assert np.abs(out - EH.forward_numpy(x, P, np.float64)).max() <= 1e-12
+    assert np.abs(lat - EH.encoder_latent_numpy(x, P, np.float64)).max() <= 1e-12
+
+
+def test_pack_rejects_bad_input(head_sds):
+    sd = synth.encoder_state_dict(136, seed=0)
+    bad = dict(sd)
+    bad["encoder.2.weight"] = bad["encoder.2.weight"][:, :100]
+    with pytest.raises(ValueError):
+        weights.pack_blob(bad, head_sds)
+    L = _lib.lib()
+    assert L.nlml_encoder_heads_packed_bytes(0, 0) == 0
+    assert L.nlml_encoder_heads_packed_bytes(136, 7) == 0
+    buf = np.zeros(16, np.uint8)
+    rc = L.nlml_encoder_heads_pack(136, 0, None, None, None, None, buf.ctypes.data_as(ctypes.c_void_p), 16)
+    assert rc != 0 and b"null" in L.nlml_last_error()
+
+
+def test_launch_entry_points_validate_before_touching_the_gpu():
+    L = _lib.lib()
+    assert L.nlml_normalize_ipd(None, 4, 1, None, None, None) == -1
+    assert L.nlml_encoder_heads_fwd(None, 1404, -1, 1404, None, 0, None, None, None, None) == -1
+    assert L.nlml_tucker_objective(None, None, 1404, None, None, None, 5, None, None, None) == -1
+    assert L.nlml_normalize_ipd(None, 0, 1, None, None, None) == 0          # empty batch is a no-op
+    assert L.nlml_tucker_objective(None, None, 1404, None, None, None, 0, None, None, None) == 0
+
+
+def test_scripted_state_dict_split_roundtrip(head_sds):
+    enc = {k: torch.from_numpy(v) for k, v in synth.encoder_state_dict(136, 0).items()}
+    combined = {f"encoder.{k}": v for k, v in enc.items()}
+    for n, sd in head_sds.items():
+        combined.update({f"{n}_network.{k}": v for k, v in sd.items()})
+    e2, h2 = weights.split_scripted_state_dict(combined)
+    assert set(e2) == set(enc) and all(torch.equal(e2[k], enc[k]) for k in enc)
+    assert all(torch.equal(h2[n][k], head_sds[n][k]) for n in head_sds for k in head_sds[n])
+    assert weights.validate_shapes(e2, h2) == 136
+
+
+def test_artefact_layout(tucker_art, repo_root):
+    assert tucker_art["W"].shape == (5, 3, 3, 3, 1404) and tucker_art["W"].dtype == np.float32
+    assert tucker_art["optimized_yaw"].shape == (3, 4) and tucker_art["U_id"].shape == (1620, 5)
+    with pytest.raises(FileNotFoundError):
+        weights.load_encoder_state_dict(os.path.join(repo_root, "models"))     # not shipped by the reference
+
+
+def test_shard_bounds_cover_exactly():
+    for n in (0, 1, 7, 16000, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            rows = [shard_bounds(n, world, r) for r in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == n
+            assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+            assert all(b - a <= per for a, b, per in rows)
+
+
+def test_no_cpu_fallback():
+    from nlml_hpe_amd import ops
+    with pytest.raises(_lib.NlmlError):
+        ops.normalize_ipd(torch.zeros(2, 468, 3))
+    with pytest.raises(_lib.NlmlError):
+        ops.encoder_heads_fwd(torch.zeros(2, 136), torch.zeros(16, dtype=torch.uint8), 136)
+
+
+def test_synth_generator_is_reproducible():
+    a, b = synth.features(64, 136, seed=3), synth.features(64, 136, seed=3)
+    assert np.array_equal(a, b) and not np.array_equal(a, synth.features(64, 136, seed=4))
+    assert (a[:, 3:6] == 0).all()
+    sd = synth.encoder_state_dict(136, 0)
+    assert sd["encoder.0.weight"].shape == (1024, 136) and abs(sd["encoder.0.weight"]).max() <= 1 / np.sqrt(136)

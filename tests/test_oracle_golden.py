@@ -1,0 +1,126 @@
+"""CPU: the oracle (numpy / torch-CPU / plain C) against the golden fixtures that were produced by
+running the reference's own Python (tests/golden/make_golden.py).  This is what pins the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nlml_hpe_amd import synth
+from oracle import c_oracle as CO
+from oracle import encoder_heads as EH
+from oracle import feature_norm as FN
+from oracle import metrics as MT
+from oracle import tucker as TK
+from oracle import video_math as VM
+
+POSE_TOL_DEG = 1e-4
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_fx1_normalise_bitexact(golden_dir):
+    g = _g(golden_dir, "fx1_normalise.npz")
+    lm = g["landmarks"]
+    assert np.array_equal(FN.normalize_ipd(lm, True), g["features_norm"])
+    assert np.array_equal(FN.normalize_ipd(lm, False), g["features_raw"])
+    assert np.array_equal(CO.normalize_ipd(lm, True), g["features_norm"])          # plain-C restatement
+    for b in (0, 3, 6):                                                              # incl. ipd == 0 and near-0 rows
+        assert np.array_equal(FN.normalize_ipd_loop(lm[b], True), g["features_norm"][b])
+    assert FN.ipd_f64(lm)[3] == 1e-6
+
+
+def test_fx2_heads_real_weights(golden_dir, head_sds):
+    g = _g(golden_dir, "fx2_heads.npz")
+    P = EH.Params(synth.encoder_state_dict(136, 0), head_sds)
+    for n in ("yaw", "pitch", "roll"):
+        y = EH.head_numpy(g[f"in_{n}"], P.heads[n], np.float32)
+        assert np.degrees(np.abs(y - g[f"out_{n}"]).max()) <= POSE_TOL_DEG
+
+
+@pytest.mark.parametrize("F", [1404, 136])
+def test_fx3_encoder_heads(F, golden_dir, head_sds):
+    g = _g(golden_dir, "fx3_encoder_heads.npz")
+    P = EH.Params(synth.encoder_state_dict(F, seed=0), head_sds)
+    x = synth.features(256, F, seed=1)
+    x[7] = 0.0
+    assert float(x.astype(np.float64).sum()) == g[f"x_crc_F{F}"][0]            # generator G regenerates the inputs
+    ref = g[f"rad_F{F}"]
+    for name, y in (("numpy32", EH.forward_numpy(x, P, np.float32)), ("numpy64", EH.forward_numpy(x, P, np.float64)),
+                    ("torch", EH.forward_torch(x, P, num_threads=1)), ("c_k_ascending", CO.encoder_heads(x, P, order=0)),
+                    ("c_mfma_order", CO.encoder_heads(x, P, order=1))):
+        assert np.degrees(np.abs(y - ref).max()) <= POSE_TOL_DEG, name
+    # batch-1 calls (how the reference runs, NLML_HPE_Test.py:262-272) agree with the batched fixture too
+    assert np.degrees(np.abs(EH.forward_numpy(x[:16], P) - g[f"rad_b1_F{F}"]).max()) <= POSE_TOL_DEG
+
+
+def _cos(art):
+    return art["optimized_yaw"][0:3], art["optimized_pitch"][0:3], art["optimized_roll"][0:3]
+
+
+def test_fx4_td_objective(golden_dir, tucker_art):
+    g = _g(golden_dir, "fx4_td_objective.npz")
+    Py, Pp, Pr = _cos(tucker_art)
+    W = tucker_art["W"]
+    e = np.array([TK.objective(p, W, x, Py, Pp, Pr) for p, x in zip(g["params"], g["x"])])
+    assert np.array_equal(e, g["err"])                                            # same einsum call => same bits
+    xh = np.stack([TK.x_hat(p, W, Py, Pp, Pr) for p in g["params"][:8]])
+    assert np.array_equal(xh, g["x_hat"])
+    eb, xhb = TK.objective_batch(g["params"], W, g["x"], Py, Pp, Pr, return_xhat=True)   # GEMM form
+    assert np.max(np.abs(eb - g["err"]) / g["err"]) <= 1e-12
+    assert np.max(np.abs(xhb[:8] - g["x_hat"])) <= 1e-12 * np.abs(g["x_hat"]).max()
+    ec, xhc = CO.tucker_objective(W, g["x"], g["params"], np.stack([Py, Pp, Pr]), want_xhat=True)   # plain C
+    assert np.max(np.abs(ec - g["err"]) / g["err"]) <= 1e-12
+    assert np.max(np.abs(xhc[:8] - g["x_hat"])) <= 1e-12 * np.abs(g["x_hat"]).max()
+
+
+def test_fx5_td_end_to_end_one_face(golden_dir, tucker_art):
+    import scipy
+    g = _g(golden_dir, "fx5_td_end_to_end.npz")
+    if scipy.__version__ != str(g["scipy_version"]):
+        pytest.skip("FX5 is tied to the scipy version that generated it")
+    Py, Pp, Pr = _cos(tucker_art)
+    i = 1                                                                          # the ~frontal face, fewest evaluations
+    (y, p, r), res = TK.test_powell(tucker_art["W"], g["x"][i], 5, Py, Pp, Pr, return_result=True)
+    assert np.allclose([y, p, r], g["deg"][i], rtol=0, atol=1e-9)                # same objective bits => same path
+    assert res.nfev == g["nfev"][i]
+
+
+def test_fx6_metrics(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "fx6_metrics.json")))
+    gt = [tuple(r) for r in g["gt"]]
+    pred = [tuple(r) for r in g["pred"]]
+    assert list(MT.compute_maev(gt, pred)) == g["maev"]
+    assert list(MT.compute_maev(g["small_gt"], g["small_pred"])) == g["small_maev"]
+    d = MT.compute_errors(gt, pred)
+    printed = dict(line.split(": ") for line in g["printed"])
+    for key, label in (("mae_yaw", "MAE (Yaw)"), ("mae_pitch", "MAE (Pitch)"), ("mae_roll", "MAE (Roll)"),
+                       ("mae_total", "Total MAE"), ("maev", "MAEV"), ("v_left", "Left vector Error (red)"),
+                       ("v_down", "Down vector Error (green)"), ("v_front", "Front vector Error (blue)"),
+                       ("std_yaw", "std (Yaw)"), ("std_pitch", "std (Pitch)"), ("std_roll", "std (Roll)")):
+        assert f"{d[key]:.2f}" == printed[label], key
+    R, l, b, f = MT.euler_to_vectors(*g["euler_in"])
+    assert np.array_equal(R, np.array(g["R"])) and np.array_equal(l, np.array(g["l"])) and np.array_equal(f, np.array(g["f"]))
+
+
+def test_fx7_video_math(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "fx7_video_math.json")))
+    gin = _g(golden_dir, "fx7_video_in.npz")
+    lm, pose = gin["landmarks"], gin["pose_rad"]
+    frames = g["frames"]
+    kept = [f["frame"] for f in frames]
+    assert set(range(len(lm))) - set(kept) == set(gin["no_face"].tolist())       # dropped frames (generatePose_on_video.py:193-196)
+    sm = VM.ema_sequence(pose[kept])
+    prev = (None, None)
+    for t, fr in enumerate(frames):
+        assert np.allclose(sm[t], fr["smoothed"], rtol=0, atol=1e-12)
+        k = fr["frame"]
+        tdx, tdy, p1, p2, p3 = VM.axes_on_face(prev[0], prev[1], g["width"], g["height"], lm[k, 1], lm[k, 33], lm[k, 263], *sm[t])
+        assert [tdx, tdy] == fr["centre"]
+        got = [[[int(tdx), int(tdy)], [int(p[0]), int(p[1])]] for p in (p1, p2, p3)]
+        assert got == fr["lines"]
+        prev = (tdx, tdy)
+    jumps = [i for i in range(1, len(frames)) if frames[i]["centre"] == frames[i - 1]["centre"]]
+    assert jumps, "fixture must exercise the >100 px jump gate"
