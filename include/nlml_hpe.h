@@ -125,6 +125,36 @@ int nlml_tucker_objective(const float* Wm, const float* x, int64_t ldx, const in
                           const double* params, const double* cos_params, int64_t N,
                           double* err, double* x_hat, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * TD end-to-end: batched, lock-step Powell minimisation of the K3 objective, entirely on device.
+ * Replaces Test() (TD_Tester.py:162-199): scipy.optimize.minimize(objective, zeros(8),
+ * method='Powell') with scipy's defaults (xtol = ftol = 1e-4, maxiter = maxfev = 8000), one
+ * independent minimisation per face; the reference spends 2-4 s per face in it.
+ *   Wm, cos_params  as for nlml_tucker_objective
+ *   x        f32[N,1404] one feature row per face, row stride ldx
+ *   x0       f64[N,8] starting points or NULL for zeros (TD_Tester.py:166)
+ *   result   f64[N,8]  minimiser (w_y, w_p, w_r in RADIANS, u_id[5]); degrees are the caller's
+ *            np.degrees(result.x)[:3] (:196-199)
+ *   fval f64[N], nfev i32[N], nit i32[N], status i32[N] (1 converged, 2 maxfev, 3 maxiter, 4 nan):
+ *            scipy's res.fun / res.nfev / res.nit; each may be NULL.
+ * The control flow is scipy 1.15.3's (restated in nlml_hpe_amd/csrc/powell.h); because the optimum
+ * is flat, last-bit differences in the objective move the final angles by up to ~1e-2 degrees
+ * (SURVEY.md D5), which is the stated tolerance of this entry point.
+ */
+int nlml_tucker_powell(const float* Wm, const float* x, int64_t ldx, const double* cos_params, int64_t N,
+                       const double* x0, double* result, double* fval, int32_t* nfev, int32_t* nit,
+                       int32_t* status, void* stream);
+
+/* Host-side stepping of the same Powell state machine (no GPU involved): the caller evaluates
+ * the objective.  Used to check the restated control flow against scipy on the CPU.
+ *   h_state: caller-allocated buffer of nlml_powell_state_bytes() bytes.
+ *   nlml_powell_step returns 1 and fills h_xeval[8] when it needs f(h_xeval) (pass it as `fin` to
+ *   the next call; `fin` of the first call is ignored), 0 when finished. */
+size_t nlml_powell_state_bytes(void);
+int    nlml_powell_init(void* h_state, const double* h_x0, double xtol, double ftol);
+int    nlml_powell_step(void* h_state, double fin, double* h_xeval);
+int    nlml_powell_result(const void* h_state, double* h_x, double* h_fval, int* h_nfev, int* h_nit, int* h_status);
+
 #ifdef __cplusplus
 }
 #endif

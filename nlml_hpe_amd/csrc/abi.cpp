@@ -6,6 +6,7 @@
 #include "../../include/nlml_hpe.h"
 #include "abi_internal.h"
 #include "layout.h"
+#include "powell.h"
 
 namespace nlml {
 static thread_local char g_err[256] = "";
@@ -78,6 +79,43 @@ int nlml_tucker_objective(const float* Wm, const float* x, int64_t ldx, const in
   if (N > 0 && (!Wm || !x || !params || !cos_params || !err)) return fail(NLML_E_BADARG, "tucker_objective: null buffer");
   if (N > 0 && ldx < NLML_F_REFERENCE) return fail(NLML_E_BADARG, "tucker_objective: ldx < 1404");
   return launch_tucker_objective(Wm, x, ldx, x_index, params, cos_params, N, err, x_hat, stream);
+}
+
+// ---- host-side stepping of the Powell state machine (powell.h) --------------------------------
+size_t nlml_powell_state_bytes(void) { return sizeof(PowellState); }
+
+int nlml_powell_init(void* h_state, const double* h_x0, double xtol, double ftol) {
+  if (!h_state || !h_x0) return fail(NLML_E_BADARG, "powell_init: null pointer");
+  powell_init(*static_cast<PowellState*>(h_state), h_x0, xtol, ftol);
+  return 0;
+}
+
+int nlml_powell_step(void* h_state, double fin, double* h_xeval) {
+  if (!h_state || !h_xeval) return fail(NLML_E_BADARG, "powell_step: null pointer");
+  PowellState& s = *static_cast<PowellState*>(h_state);
+  const bool need = powell_step(s, fin);
+  if (need) std::memcpy(h_xeval, s.xeval, sizeof s.xeval);
+  return need ? 1 : 0;
+}
+
+int nlml_powell_result(const void* h_state, double* h_x, double* h_fval, int* h_nfev, int* h_nit, int* h_status) {
+  if (!h_state || !h_x) return fail(NLML_E_BADARG, "powell_result: null pointer");
+  const PowellState& s = *static_cast<const PowellState*>(h_state);
+  std::memcpy(h_x, s.x, sizeof s.x);
+  if (h_fval) *h_fval = s.fval;
+  if (h_nfev) *h_nfev = s.nfev;
+  if (h_nit) *h_nit = s.iter;
+  if (h_status) *h_status = s.status;
+  return 0;
+}
+
+int nlml_tucker_powell(const float* Wm, const float* x, int64_t ldx, const double* cos_params, int64_t N,
+                       const double* x0, double* result, double* fval, int32_t* nfev, int32_t* nit,
+                       int32_t* status, void* stream) {
+  if (N < 0) return fail(NLML_E_BADARG, "tucker_powell: negative N");
+  if (N > 0 && (!Wm || !x || !cos_params || !result)) return fail(NLML_E_BADARG, "tucker_powell: null buffer");
+  if (N > 0 && ldx < NLML_F_REFERENCE) return fail(NLML_E_BADARG, "tucker_powell: ldx < 1404");
+  return launch_tucker_powell(Wm, x, ldx, cos_params, N, x0, result, fval, nfev, nit, status, stream);
 }
 
 }  // extern "C"

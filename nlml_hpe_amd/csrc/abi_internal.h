@@ -26,4 +26,9 @@ int launch_tucker_objective(const float* Wm, const float* x, int64_t ldx, const 
                             const double* params, const double* cos_params, int64_t N,
                             double* err, double* x_hat, void* stream);
 
+// tucker_powell.hip
+int launch_tucker_powell(const float* Wm, const float* x, int64_t ldx, const double* cos_params, int64_t N,
+                         const double* x0, double* result, double* fval, int32_t* nfev, int32_t* nit,
+                         int32_t* status, void* stream);
+
 }  // namespace nlml

@@ -189,3 +189,37 @@ try:
 except Exception as _e:  # pragma: no cover - registration is a convenience; the functions above are the API
     import warnings
     warnings.warn(f"torch.ops.nlml_hpe registration skipped: {_e}")
+
+
+def tucker_powell(Wm: torch.Tensor, x: torch.Tensor, cos_params: torch.Tensor, x0: torch.Tensor | None = None):
+    """Batched Test() (TD_Tester.py:162-199): one Powell minimisation per row of x, on device.
+
+    Returns dict(x=f64[N,8] (w_y,w_p,w_r radians + u_id), fun=f64[N], nfev=i32[N], nit=i32[N], status=i32[N]).
+    """
+    _need_cuda(Wm, "Wm", torch.float32)
+    _need_cuda(x, "x", torch.float32)
+    _need_cuda(cos_params, "cos_params", torch.float64)
+    if tuple(Wm.shape) != (135, F_REF):
+        raise ValueError(f"Wm: expected [135,1404], got {tuple(Wm.shape)}")
+    if x.dim() != 2 or x.shape[1] != F_REF:
+        raise ValueError(f"x: expected [N,1404], got {tuple(x.shape)}")
+    if tuple(cos_params.shape) != (3, 3, 4):
+        raise ValueError(f"cos_params: expected [3,3,4], got {tuple(cos_params.shape)}")
+    Wm, x, cos_params = Wm.contiguous(), x.contiguous(), cos_params.contiguous()
+    N = x.shape[0]
+    if x0 is not None:
+        _need_cuda(x0, "x0", torch.float64)
+        if tuple(x0.shape) != (N, 8):
+            raise ValueError(f"x0: expected [{N},8], got {tuple(x0.shape)}")
+        x0 = x0.contiguous()
+    dev = x.device
+    res = torch.empty((N, 8), dtype=torch.float64, device=dev)
+    fun = torch.empty((N,), dtype=torch.float64, device=dev)
+    nfev = torch.empty((N,), dtype=torch.int32, device=dev)
+    nit = torch.empty((N,), dtype=torch.int32, device=dev)
+    status = torch.empty((N,), dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().nlml_tucker_powell(Wm.data_ptr(), x.data_ptr(), F_REF, cos_params.data_ptr(), N,
+                                             x0.data_ptr() if x0 is not None else None, res.data_ptr(), fun.data_ptr(),
+                                             nfev.data_ptr(), nit.data_ptr(), status.data_ptr(), _stream_ptr()),
+               "nlml_tucker_powell")
+    return {"x": res, "fun": fun, "nfev": nfev, "nit": nit, "status": status}

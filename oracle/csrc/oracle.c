@@ -102,8 +102,35 @@ void oracle_encoder_heads_f32(const float* x, int64_t B, int F, const float* con
 /* ---- TD_Tester.py:25-28 (func), :31-58 (objective) ---------------------------------------
  * Wm f32[135,1404]; x f32[N,1404]; params f64[N,8]; cosp f64[3,3,4]; err f64[N]; xhat f64[N,1404]|NULL.
  * x_hat[m] = sum_q c[q]*Wm[q][m], q ascending in one fma chain (the HIP kernel's order). */
+/* device_order != 0: the residual is summed in the HIP kernel's order (tucker_objective.hip /
+ * tucker_powell.hip): thread t of 256 owns columns t, t+256, ... (fma chain), then a 64-lane xor
+ * butterfly per wave (offsets 32..1), then (w0+w1)+(w2+w3); the result is then bit-identical to the
+ * GPU's, which lets the device-side Powell run be replayed exactly on the CPU. */
+static double residual_device_order(const float* xrow, const double* acc) {
+  double s[256];
+  for (int t = 0; t < 256; ++t) {
+    double v = 0.0;
+    for (int j = 0; j < 6; ++j) {
+      const int m = t + 256 * j;
+      if (m < 1404) { const double r = (double)xrow[m] - acc[m]; v = fma(r, r, v); }
+    }
+    s[t] = v;
+  }
+  double red[4];
+  for (int w = 0; w < 4; ++w) {
+    double v[64], n[64];
+    memcpy(v, s + 64 * w, sizeof v);
+    for (int off = 32; off > 0; off >>= 1) {
+      for (int l = 0; l < 64; ++l) n[l] = v[l] + v[l ^ off];
+      memcpy(v, n, sizeof v);
+    }
+    red[w] = v[0];
+  }
+  return 0.5 * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
 void oracle_tucker_objective(const float* Wm, const float* x, const double* params, const double* cosp,
-                             int64_t N, double* err, double* xhat) {
+                             int64_t N, double* err, double* xhat, int device_order) {
 #pragma omp parallel for schedule(static)
   for (int64_t n = 0; n < N; ++n) {
     const double* p = params + n * 8;
@@ -117,13 +144,15 @@ void oracle_tucker_objective(const float* Wm, const float* x, const double* para
     for (int q = 0; q < 135; ++q)
       c[q] = ((p[3 + q / 27] * f[0][(q / 9) % 3]) * f[1][(q / 3) % 3]) * f[2][q % 3];
     double s = 0.0;
+    double accv[1404];
     for (int m = 0; m < 1404; ++m) {
       double acc = 0.0;
       for (int q = 0; q < 135; ++q) acc = fma(c[q], (double)Wm[(size_t)q * 1404 + m], acc);
       if (xhat) xhat[n * 1404 + m] = acc;
+      accv[m] = acc;
       const double r = (double)x[n * 1404 + m] - acc;
       s += r * r;
     }
-    err[n] = 0.5 * s;                                                           /* :49 */
+    err[n] = device_order ? residual_device_order(x + n * 1404, accv) : 0.5 * s;   /* :49 */
   }
 }

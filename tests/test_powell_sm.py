@@ -1,0 +1,72 @@
+"""CPU: the restated Powell/Brent state machine (nlml_hpe_amd/csrc/powell.h), stepped on the host with
+a Python objective, must follow scipy.optimize.minimize(method='Powell') EXACTLY -- same trial points,
+same number of evaluations, same result bits -- when it is given the same objective values."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+from nlml_hpe_amd.powell_host import minimize_powell
+from oracle import tucker as TK
+
+
+def _scipy(fun, x0):
+    pts = []
+
+    def f(x):
+        pts.append(np.array(x, dtype=np.float64))
+        return fun(x)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = minimize(f, x0, method="Powell")
+    return res, pts
+
+
+def _rosen8(x):
+    return float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2))
+
+
+def _quad8(x):
+    a = np.arange(1, 9, dtype=np.float64)
+    return float(np.sum(a * (x - 0.3 * a) ** 2) + 0.5 * x[0] * x[5])
+
+
+def _bumpy8(x):
+    return float(np.sum(np.cos(3 * x) + 0.1 * x ** 2) + np.abs(x[2] - 0.2))
+
+
+def _flat_dir8(x):                      # ignores half of the variables: zero-progress line searches
+    return float((x[0] - 1) ** 2 + (x[1] + 2) ** 4 + np.sin(x[2]) ** 2)
+
+
+def _nan_region8(x):
+    return float(np.sum((x - 0.5) ** 2)) if x[0] < 0.4 else float("nan")
+
+
+@pytest.mark.parametrize("fun,x0", [
+    (_rosen8, np.zeros(8)), (_rosen8, np.linspace(-1.2, 1.0, 8)), (_quad8, np.zeros(8)),
+    (_bumpy8, np.full(8, 0.7)), (_flat_dir8, np.zeros(8)), (_nan_region8, np.zeros(8)),
+])
+def test_state_machine_follows_scipy(fun, x0):
+    ref, ref_pts = _scipy(fun, x0)
+    pts = []
+    got = minimize_powell(fun, x0, record=pts)
+    assert got.nfev == ref.nfev and got.nit == ref.nit
+    assert len(pts) == len(ref_pts)
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(pts, ref_pts)), "trial points diverge from scipy"
+    assert np.array_equal(got.x, ref.x, equal_nan=True)
+    assert got.fun == ref.fun or (np.isnan(got.fun) and np.isnan(ref.fun))
+
+
+def test_state_machine_on_the_tucker_objective(golden_dir, tucker_art):
+    """The reference's own use: Test() (TD_Tester.py:162-199) on a grid-reconstructed face (FX5)."""
+    g = np.load(os.path.join(golden_dir, "fx5_td_end_to_end.npz"))
+    W = tucker_art["W"]
+    Py, Pp, Pr = tucker_art["optimized_yaw"][:3], tucker_art["optimized_pitch"][:3], tucker_art["optimized_roll"][:3]
+    i = 1
+    x = g["x"][i]
+    got = minimize_powell(lambda p: TK.objective(p, W, x, Py, Pp, Pr), np.zeros(8))
+    assert got.nfev == g["nfev"][i]
+    assert np.allclose(np.degrees(got.x[:3]), g["deg"][i], rtol=0, atol=1e-9)
