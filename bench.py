@@ -247,6 +247,24 @@ def extra_workloads(ops, synth, weights, dev, heads, blob, raw, feats, B):
     ms = time_kernel(lambda: ops.tucker_objective(Wm, feats[:N], P, cp), 20)
     ex["k3_tucker_objective"] = {"evals_per_sec": N / ms * 1e3, "tflops_f64": N * TUCKER_FLOP_PER_EVAL / ms / 1e9,
                                  "f64_frac": N * TUCKER_FLOP_PER_EVAL / ms / 1e9 / PEAK_F64_TFLOPS, "n": N}
+    # TD end-to-end (TD_Tester.Test): device-side lock-step Powell, one minimisation per face
+    from oracle import tucker as TK    # test-infra helper only used to synthesise grid faces (inputs), not measured
+    idx = synth.tucker_grid_indices(1024, seed=2)
+    Xg = np.stack([TK.grid_reconstruction(art["W"], art["U_id"][i], art["U_yaw"][j], art["U_pitch"][k], art["U_roll"][l])
+                   for i, j, k, l in idx])
+    Xg = (Xg.astype(np.float64) + 1e-3 * synth.rng(2, 77).standard_normal(Xg.shape)).astype(np.float32)
+    Xg = torch.from_numpy(Xg).to(dev)
+    ops.tucker_powell(Wm, Xg[:64], cp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = ops.tucker_powell(Wm, Xg, cp)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nf = res["nfev"].double()
+    ex["td_powell_end_to_end"] = {"faces": int(Xg.shape[0]), "seconds": dt, "faces_per_sec": Xg.shape[0] / dt,
+                                  "mean_nfev": float(nf.mean()), "max_nfev": float(nf.max()),
+                                  "face_evals_per_sec": float(nf.sum()) / dt,
+                                  "converged_frac": float((res["status"] == 1).double().mean())}
     return ex
 
 

@@ -103,21 +103,22 @@ void oracle_encoder_heads_f32(const float* x, int64_t B, int F, const float* con
  * Wm f32[135,1404]; x f32[N,1404]; params f64[N,8]; cosp f64[3,3,4]; err f64[N]; xhat f64[N,1404]|NULL.
  * x_hat[m] = sum_q c[q]*Wm[q][m], q ascending in one fma chain (the HIP kernel's order). */
 /* device_order != 0: the residual is summed in the HIP kernel's order (tucker_objective.hip /
- * tucker_powell.hip): thread t of 256 owns columns t, t+256, ... (fma chain), then a 64-lane xor
- * butterfly per wave (offsets 32..1), then (w0+w1)+(w2+w3); the result is then bit-identical to the
+ * tucker_powell.hip): thread t of 512 owns columns t, t+512, t+1024 (fma chain), then a 64-lane xor
+ * butterfly per wave (offsets 32..1), then ((w0+w1)+(w2+w3))+((w4+w5)+(w6+w7)); the result is then bit-identical to the
  * GPU's, which lets the device-side Powell run be replayed exactly on the CPU. */
 static double residual_device_order(const float* xrow, const double* acc) {
-  double s[256];
-  for (int t = 0; t < 256; ++t) {
+  enum { NT = 512, CPT = 3, NW = 8 };
+  double s[NT];
+  for (int t = 0; t < NT; ++t) {
     double v = 0.0;
-    for (int j = 0; j < 6; ++j) {
-      const int m = t + 256 * j;
+    for (int j = 0; j < CPT; ++j) {
+      const int m = t + NT * j;
       if (m < 1404) { const double r = (double)xrow[m] - acc[m]; v = fma(r, r, v); }
     }
     s[t] = v;
   }
-  double red[4];
-  for (int w = 0; w < 4; ++w) {
+  double red[NW];
+  for (int w = 0; w < NW; ++w) {
     double v[64], n[64];
     memcpy(v, s + 64 * w, sizeof v);
     for (int off = 32; off > 0; off >>= 1) {
@@ -126,7 +127,7 @@ static double residual_device_order(const float* xrow, const double* acc) {
     }
     red[w] = v[0];
   }
-  return 0.5 * ((red[0] + red[1]) + (red[2] + red[3]));
+  return 0.5 * (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
 }
 
 void oracle_tucker_objective(const float* Wm, const float* x, const double* params, const double* cosp,
