@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Evaluate the encoder+heads model on a validation set -- MI355X batched counterpart of the
+reference's NLML_HPE_Test.py (NLML_HPE_Tester, :182): same configs, same metrics block, same
+model-file lookup; the per-image FaceMesh loop (batch 1, three .item() syncs per face) becomes one
+fused HIP launch per batch over pre-extracted landmarks.
+
+    python NLML_HPE_Test.py [--device cuda:0] [--batch 65536]
+    torchrun --nproc-per-node N NLML_HPE_Test.py      # faces sharded over N GPUs, poses all-gathered
+
+val_set (configs/config_NLML_HPE_Test.yaml): "landmarks_npz" (val_set_path -> .npz with `landmarks`
+f32[N,468,3] and `pose` f32[N,3] degrees) or "synthetic" (seeded generator, synthetic_rows faces).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+import warnings
+
+import numpy as np
+import torch
+
+from nlml_hpe_amd import metrics, synth
+from nlml_hpe_amd.distributed import gather_poses, shard_bounds
+from nlml_hpe_amd.entrypoints import load_config, resolve_model
+
+
+def NLML_HPE_Tester(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--device", default=None)
+    ap.add_argument("--batch", type=int, default=None)
+    args = ap.parse_args(argv)
+    warnings.filterwarnings("default")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device(args.device or f"cuda:{local}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    bins = load_config("configs/config_EncoderTrainer.yaml")
+    cfg = load_config("configs/config_NLML_HPE_Test.yaml")
+    lo = np.array([bins["yaw_bins"]["min_bin"], bins["pitch_bins"]["min_bin"], bins["roll_bins"]["min_bin"]], dtype=np.float64)
+    hi = np.array([bins["yaw_bins"]["max_bin"], bins["pitch_bins"]["max_bin"], bins["roll_bins"]["max_bin"]], dtype=np.float64)
+    intervals = [[tuple(x) for x in cfg[k]] for k in ("yaw_intervals", "pitch_intervals", "roll_intervals")]
+
+    model = resolve_model(device, input_size=bins["input_size"])
+    model.eval()
+
+    if cfg["val_set"] == "landmarks_npz":
+        data = np.load(cfg["val_set_path"])
+        raw_all, gt_all = np.asarray(data["landmarks"], np.float32), np.asarray(data["pose"], np.float64)
+    elif cfg["val_set"] == "synthetic":
+        n = int(cfg.get("synthetic_rows", 256))
+        raw_all, gt_all = synth.raw_landmarks(n, seed=1), synth.poses_deg(n, seed=4)
+    else:
+        raise SystemExit(f'val_set "{cfg["val_set"]}" needs image decoding + MediaPipe, unavailable here; '
+                         'use "landmarks_npz" or "synthetic"')
+
+    n_total = raw_all.shape[0]
+    start, stop, _ = shard_bounds(n_total, world, rank)
+    batch = int(args.batch or cfg.get("batch_size", 65536))
+    t0 = time.time()
+    poses, valids = [], []
+    for b0 in range(start, stop, batch):
+        raw = torch.from_numpy(raw_all[b0:min(b0 + batch, stop)]).to(device)
+        pose, valid = model.from_landmarks(raw, normalize=True, return_valid=True)
+        poses.append(pose)
+        valids.append(valid)
+    pose = torch.cat(poses) if poses else torch.zeros((0, 3), device=device)
+    valid = torch.cat(valids) if valids else torch.zeros((0,), dtype=torch.bool, device=device)
+    if world > 1:
+        pose = gather_poses(pose, n_total)
+        valid = gather_poses(valid.float().unsqueeze(1).expand(-1, 3).contiguous(), n_total)[:, 0] > 0.5
+    torch.cuda.synchronize()
+    elapsed = time.time() - t0
+
+    if rank == 0:
+        pred = np.round(np.degrees(pose.cpu().numpy().astype(np.float64)), 3)       # round(np.degrees(.item()), 3), :273
+        in_range = ((gt_all >= lo) & (gt_all <= hi)).all(axis=1)                     # GT range filter, :252
+        keep = in_range & valid.cpu().numpy()                                         # zero rows = no face, :257-260
+        print(f"processed {int(keep.sum())} of {n_total} samples "
+              f"({int((~valid.cpu().numpy()).sum())} without landmarks, {int((~in_range).sum())} out of range)")
+        print("=============================Metrics for pred_angles_NLML_HPE:")
+        res = metrics.compute_errors(gt_all[keep], pred[keep])
+        print("\n======================================================================")
+        for k, v in metrics.compute_interval_mae(gt_all[keep], pred[keep], *intervals).items():
+            print(f"{k}: {v:.3f}")
+        h, m, s = int(elapsed // 3600), int((elapsed % 3600) // 60), elapsed % 60
+        print(f"Average Elapsed time for test: {h:02}:{m:02}:{s:05.2f}  ({n_total / max(elapsed, 1e-9):,.0f} faces/s)")
+        return res
+    return None
+
+
+if __name__ == "__main__":
+    NLML_HPE_Tester()

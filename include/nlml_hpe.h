@@ -145,6 +145,24 @@ int nlml_tucker_powell(const float* Wm, const float* x, int64_t ldx, const doubl
                        const double* x0, double* result, double* fval, int32_t* nfev, int32_t* nit,
                        int32_t* status, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K4  Video post-processing for S concurrent streams, one frame tick per call.
+ * Replaces, per stream (generatePose_on_video.py): round(np.degrees(.), 2) (:211), the exponential
+ * smoothing s = alpha*new + (1-alpha)*s seeded by the first prediction (:215-224, alpha 0.4 at :179),
+ * and visualize_axes_on_face (:73-124): face centre from landmarks 1/33/263 x frame size, the
+ * 100-px jump gate, and the three axis end points (size 80).
+ *   pose_rad  f32[S,3]      this tick's model output (radians)
+ *   raw       f32[S,468,3]  this tick's FaceMesh landmarks (only 1, 33, 263 are read)
+ *   valid     u8[S] or NULL 0 = no face in this stream's frame: state and outputs untouched (:193-196)
+ *   state     f64[S,6]      persistent: smoothed yaw/pitch/roll, previous centre x/y, prediction count;
+ *                           zero-initialise before the first tick
+ *   smoothed  f64[S,3] degrees; centre f64[S,2] pixels; endpoints f64[S,3,2] pixels (x,y of the red,
+ *             green, blue axis tips; the reference draws int() of them)
+ */
+int nlml_video_post(const float* pose_rad, const float* raw, const uint8_t* valid, int64_t S,
+                    double frame_w, double frame_h, double alpha, double max_jump, double size,
+                    double* state, double* smoothed, double* centre, double* endpoints, void* stream);
+
 /* Host-side stepping of the same Powell state machine (no GPU involved): the caller evaluates
  * the objective.  Used to check the restated control flow against scipy on the CPU.
  *   h_state: caller-allocated buffer of nlml_powell_state_bytes() bytes.

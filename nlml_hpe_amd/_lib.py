@@ -31,6 +31,8 @@ SYMBOLS = {
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlml_tucker_powell": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nlml_video_post": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlml_powell_state_bytes": (C.c_size_t, []),
     "nlml_powell_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double]),
     "nlml_powell_step": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),

@@ -1,0 +1,52 @@
+"""Batched video post-processing: S concurrent streams, state resident on the device.
+
+Mirror of the per-frame tail of process_video (generatePose_on_video.py:198-229): rounding, EMA
+smoothing, face centre with the jump gate and the axis end points, for many streams per tick in one
+HIP launch (csrc/video_post.hip).  Capture / drawing / encoding (cv2) are out of scope.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, ops
+
+ALPHA = 0.4              # generatePose_on_video.py:179
+MAX_CENTER_JUMP = 100.0  # :136
+AXIS_SIZE = 80.0         # :73
+
+
+class VideoPoseTracker:
+    def __init__(self, model, streams: int, frame_w: int, frame_h: int, alpha: float = ALPHA,
+                 max_jump: float = MAX_CENTER_JUMP, size: float = AXIS_SIZE):
+        self.model, self.S = model, int(streams)
+        self.frame_w, self.frame_h = float(frame_w), float(frame_h)
+        self.alpha, self.max_jump, self.size = float(alpha), float(max_jump), float(size)
+        dev = model.device
+        self.state = torch.zeros((self.S, 6), dtype=torch.float64, device=dev)
+        self.smoothed = torch.zeros((self.S, 3), dtype=torch.float64, device=dev)
+        self.centre = torch.zeros((self.S, 2), dtype=torch.float64, device=dev)
+        self.endpoints = torch.zeros((self.S, 3, 2), dtype=torch.float64, device=dev)
+
+    def post(self, pose_rad: torch.Tensor, raw: torch.Tensor, valid: torch.Tensor | None = None):
+        """One tick given the model outputs: updates state; returns (smoothed deg, centre, endpoints) views."""
+        ops._need_cuda(pose_rad, "pose_rad", torch.float32)
+        ops._need_cuda(raw, "raw", torch.float32)
+        if tuple(pose_rad.shape) != (self.S, 3) or tuple(raw.shape) != (self.S, 468, 3):
+            raise ValueError(f"expected pose [{self.S},3] and landmarks [{self.S},468,3]")
+        v8 = None
+        if valid is not None:
+            if tuple(valid.shape) != (self.S,):
+                raise ValueError("valid: expected [S]")
+            v8 = valid.to(torch.uint8).contiguous()
+        _lib.check(_lib.lib().nlml_video_post(
+            pose_rad.contiguous().data_ptr(), raw.contiguous().data_ptr(), v8.data_ptr() if v8 is not None else None,
+            self.S, self.frame_w, self.frame_h, self.alpha, self.max_jump, self.size, self.state.data_ptr(),
+            self.smoothed.data_ptr(), self.centre.data_ptr(), self.endpoints.data_ptr(), ops._stream_ptr()),
+            "nlml_video_post")
+        return self.smoothed, self.centre, self.endpoints
+
+    def tick(self, raw: torch.Tensor):
+        """raw landmarks f32[S,468,3] of this tick (all-zero rows = no face) -> (smoothed, centre, endpoints, valid)."""
+        pose, valid = self.model.from_landmarks(raw, normalize=True, return_valid=True)
+        sm, c, ep = self.post(pose, raw, valid)
+        return sm, c, ep, valid

@@ -249,3 +249,66 @@ def test_device_powell_replays_exactly_on_the_cpu(tucker_art, golden_dir, device
         assert host.nfev == info["nfev"][i]
         assert np.array_equal(host.x, info["x"][i])
         assert host.fun == info["fun"][i]
+
+
+def test_fx7_video_post_on_device(head_sds, golden_dir, device):
+    """K4 against what the reference's own process_video loop produced (FX7): smoothed angles, centre
+    with the jump gate, integer axis end points, skipped no-face frames."""
+    import json
+    from nlml_hpe_amd.video import VideoPoseTracker
+    g = json.load(open(os.path.join(golden_dir, "fx7_video_math.json")))
+    gin = np.load(os.path.join(golden_dir, "fx7_video_in.npz"))
+    lm, pose = gin["landmarks"], gin["pose_rad"]
+    T = lm.shape[0]
+
+    class _M:                      # the tracker only needs .device from the model when post() is driven directly
+        pass
+    m = _M()
+    m.device = device
+    tr = VideoPoseTracker(m, 1, g["width"], g["height"])
+    recs = {f["frame"]: f for f in g["frames"]}
+    no_face = set(gin["no_face"].tolist())
+    for t in range(T):
+        valid = torch.tensor([t not in no_face], device=device)
+        sm, c, ep = tr.post(torch.from_numpy(pose[t:t + 1]).to(device), torch.from_numpy(lm[t:t + 1]).to(device), valid)
+        if t in no_face:
+            continue
+        fr = recs[t]
+        assert np.allclose(sm.cpu().numpy()[0], fr["smoothed"], rtol=0, atol=1e-9)
+        cc = c.cpu().numpy()[0]
+        assert np.allclose(cc, fr["centre"], rtol=0, atol=1e-9)
+        e = ep.cpu().numpy()[0]
+        got = [[[int(cc[0]), int(cc[1])], [int(e[k, 0]), int(e[k, 1])]] for k in range(3)]
+        assert got == fr["lines"], (t, got, fr["lines"])
+
+
+def test_metrics_on_device_match_fx6(golden_dir, device):
+    import json
+    from nlml_hpe_amd import metrics
+    g = json.load(open(os.path.join(golden_dir, "fx6_metrics.json")))
+    gt = torch.tensor(g["gt"], dtype=torch.float64, device=device)
+    pr = torch.tensor(g["pred"], dtype=torch.float64, device=device)
+    assert np.allclose(metrics.compute_maev(gt, pr), g["maev"], rtol=0, atol=1e-9)
+    d = metrics.compute_errors(gt, pr, verbose=False)
+    printed = dict(line.split(": ") for line in g["printed"])
+    assert f'{d["mae_yaw"]:.2f}' == printed["MAE (Yaw)"] and f'{d["std_roll"]:.2f}' == printed["std (Roll)"]
+    assert f'{d["maev"]:.2f}' == printed["MAEV"]
+
+
+def test_entry_points_run(repo_root, device, tmp_path, capsys):
+    import subprocess
+    import sys
+    lm = synth.raw_landmarks(3, seed=31)
+    np.save(tmp_path / "faces.npy", lm)
+    env = dict(os.environ, PYTHONPATH=repo_root)
+    for cmd in (["NLML_HPE_Test.py"], ["TD_Inference.py", "--image_path", str(tmp_path / "faces.npy")],
+                ["generatePose_on_video.py", "--source", "synthetic", "--save_output", "True", "--output_path", str(tmp_path / "p.npz")],
+                ["NLML_HPE_Model_Builder.py", "--synthetic-encoder-seed", "0", "--out", str(tmp_path / "m.nlml")]):
+        res = subprocess.run([sys.executable] + cmd, cwd=repo_root, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, (cmd, res.stdout[-2000:], res.stderr[-2000:])
+        if cmd[0] == "NLML_HPE_Test.py":
+            assert "MAE (Yaw)" in res.stdout and "MAEV" in res.stdout
+        if cmd[0] == "TD_Inference.py":
+            assert res.stdout.count("Estimated yaw in degree") == 3
+    out = np.load(tmp_path / "p.npz")
+    assert out["smoothed_deg"].shape == (90, 64, 3) and np.isfinite(out["endpoints"]).all()
