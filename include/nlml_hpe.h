@@ -94,12 +94,16 @@ int nlml_encoder_heads_fwd(const float* x, int64_t ldx, int64_t B, int F,
                            const void* blob, size_t blob_bytes,
                            float* out, float* latent, uint8_t* valid, void* stream);
 
-/* Test hook: as nlml_encoder_heads_fwd, and also writes pre_tanh f32[B,64] = the Linear(128,64)
- * outputs BEFORE the Tanh (Model_Builder.py:49-50).  Everything up to there is pure f32 fma, so
- * it is compared bit for bit against the C oracle's fmaf chain (tests/test_gpu_parity.py). */
+/* Diagnostic build of nlml_encoder_heads_fwd (x 16-byte aligned, F % 4 == 0).  It also writes
+ *   pre_tanh f32[B,64] (or NULL): the Linear(128,64) outputs BEFORE the Tanh (Model_Builder.py:49-50);
+ *            everything up to there is pure f32 fma, so it is compared bit for bit against the C
+ *            oracle's fmaf chain (tests/test_gpu_parity.py);
+ *   stamps   u64[ceil(B/32),4,16] (or NULL): per-wave s_memtime at the stage boundaries, for the
+ *            cycle-share breakdown in profiles/ (never a run-time figure). */
 int nlml_encoder_heads_fwd_debug(const float* x, int64_t ldx, int64_t B, int F,
                                  const void* blob, size_t blob_bytes,
-                                 float* out, float* latent, float* pre_tanh, void* stream);
+                                 float* out, float* latent, float* pre_tanh,
+                                 unsigned long long* stamps, void* stream);
 
 /* Fused K1+K2: raw landmarks in, pose out; the normalised features never touch HBM.
  *   raw f32[B,468,3]; valid u8[B] or NULL as in nlml_normalize_ipd. F must be 1404. */

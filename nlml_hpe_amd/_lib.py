@@ -24,7 +24,7 @@ SYMBOLS = {
     "nlml_encoder_heads_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlml_encoder_heads_fwd_debug": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
-                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlml_landmarks_to_pose": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlml_tucker_objective": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -55,21 +55,21 @@ int nlml_encoder_heads_fwd(const float* x, int64_t ldx, int64_t B, int F, const 
                            float* out, float* latent, uint8_t* valid, void* stream) {
   if (int rc = check_blob_args(B, F, blob, blob_bytes, out)) return rc;
   if (B > 0 && (!x || ldx < F)) return fail(NLML_E_BADARG, "encoder_heads: null x or ldx < F");
-  return launch_encoder_heads_f32(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, nullptr, stream);
+  return launch_encoder_heads_f32(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, nullptr, nullptr, stream);
 }
 
 int nlml_encoder_heads_fwd_debug(const float* x, int64_t ldx, int64_t B, int F, const void* blob, size_t blob_bytes,
-                                 float* out, float* latent, float* pre_tanh, void* stream) {
+                                 float* out, float* latent, float* pre_tanh, unsigned long long* stamps, void* stream) {
   if (int rc = check_blob_args(B, F, blob, blob_bytes, out)) return rc;
   if (B > 0 && (!x || ldx < F)) return fail(NLML_E_BADARG, "encoder_heads: null x or ldx < F");
-  return launch_encoder_heads_f32(x, ldx, nullptr, 0, B, F, blob, out, latent, nullptr, pre_tanh, stream);
+  return launch_encoder_heads_f32(x, ldx, nullptr, 0, B, F, blob, out, latent, nullptr, pre_tanh, stamps, stream);
 }
 
 int nlml_landmarks_to_pose(const float* raw, int64_t B, int normalize, const void* blob, size_t blob_bytes,
                            float* out, float* latent, uint8_t* valid, void* stream) {
   if (int rc = check_blob_args(B, NLML_F_REFERENCE, blob, blob_bytes, out)) return rc;
   if (B > 0 && !raw) return fail(NLML_E_BADARG, "landmarks_to_pose: null raw");
-  return launch_encoder_heads_f32(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, nullptr, stream);
+  return launch_encoder_heads_f32(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, nullptr, nullptr, stream);
 }
 
 int nlml_tucker_objective(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,

@@ -17,7 +17,7 @@ int pack_f32(int F, const float* const enc_w[6], const float* const enc_b[6],
 // encoder_heads.hip
 int launch_encoder_heads_f32(const float* x, int64_t ldx, const float* raw, int normalize,
                              int64_t B, int F, const void* blob, float* out, float* latent,
-                             uint8_t* valid, float* pre_tanh, void* stream);
+                             uint8_t* valid, float* pre_tanh, unsigned long long* stamps, void* stream);
 // normalize_ipd.hip
 int launch_normalize_ipd(const float* raw, int64_t B, int normalize, float* out, uint8_t* valid,
                          void* stream);

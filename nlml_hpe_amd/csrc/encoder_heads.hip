@@ -44,7 +44,8 @@ struct EncArgs {
   float* out;           // [B,3]
   float* latent;        // [B,9] or null
   uint8_t* valid;       // [B] or null
-  float* pre_tanh;      // [B,64] or null: E4 accumulators before the Tanh (test hook)
+  float* pre_tanh;      // [B,64] or null: E4 accumulators before the Tanh (test hook, DBG build only)
+  unsigned long long* stamps;  // [blocks,4 waves,16] s_memtime at stage boundaries (DBG build only)
 };
 
 template <int ACT>
@@ -83,8 +84,9 @@ __device__ __forceinline__ void mfma_step(f32x16 (&acc)[NB], const f32x4 (&w)[NB
 // step s and then waits for them at once (34 % of wave cycles parked in s_waitcnt, profiles/r01):
 // so the loop is unrolled over a ring of R register buffers with the loads of step s+D (D = R-1)
 // pinned ABOVE the MFMAs of step s by sched_barrier.  R is chosen per NB so that D steps of MFMA
-// work (NB*256 cycles each) cover an L2/MALL round trip: NB 8 -> R 2, NB 4 -> R 4, NB <= 2 -> R 8.
-template <int NB> struct Ring { static constexpr int R = NB >= 8 ? 2 : (NB >= 4 ? 4 : 8); };
+// work (NB*256 cycles each) cover an L2 MISS (Infinity-Cache round trip, ~2 us under load: the first CU of an
+// XCD to touch a weight line pays it): NB 8 -> R 4 (6k cycles ahead), NB <= 4 -> R 8 (>= 7k / 3.5k / 1.8k cycles).
+template <int NB> struct Ring { static constexpr int R = NB >= 8 ? 4 : 8; };
 
 // K loop with the input image resident in LDS.  `w` already points at this lane's first
 // fragment of the job, `in` at this lane's (face row, k-half) of the input image.  Loads run up to
@@ -236,11 +238,14 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const EncArgs& a, int64_t
 
   gload(0);
   lwrite(0, 0);
-  // weight ring of 2 (even K steps in slot 0, odd in slot 1; a slab holds 8 steps, so the parity is
-  // static inside the unrolled slab body) and an x ring of 2 inside the slab
-  f32x4 w0[NB], w1[NB];
+  // weight ring of R0 = 4 slots: K step ks lives in slot ks % 4; a full slab holds 8 steps, so the slot
+  // of every step is static inside the unrolled slab body.  x ring of 2 inside the slab.
+  constexpr int R0 = Ring<NB>::R, D0 = R0 - 1;
+  f32x4 wr[R0][NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) w0[nb] = w[nb * 64];
+  for (int d = 0; d < D0; ++d)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) wr[d][nb] = w[(d * NB + nb) * 64];
   __syncthreads();
 
   int ks = 0;
@@ -250,31 +255,18 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const EncArgs& a, int64_t
     const float* xrow = xs + (s & 1) * (32 * S_XS) + c.f * S_XS + 4 * c.h;
     int nk = k8_total - ks;
     nk = nk > 8 ? 8 : nk;
-    f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow), x1;
+    f32x4 xr[2];
+    xr[0] = *reinterpret_cast<const f32x4*>(xrow);
 #pragma unroll
-    for (int kk = 0; kk < 8; kk += 2) {
+    for (int kk = 0; kk < 8; ++kk) {
       if (kk < nk) {
-        const f32x4* wp = w + (size_t)(ks + kk + 1) * (NB * 64);
+        const f32x4* wp = w + (size_t)(ks + kk + D0) * (NB * 64);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) w1[nb] = wp[nb * 64];
-        x1 = *reinterpret_cast<const f32x4*>(xrow + 8 * (kk + 1 < nk ? kk + 1 : kk));
+        for (int nb = 0; nb < NB; ++nb) wr[(kk + D0) % R0][nb] = wp[nb * 64];
+        xr[(kk + 1) & 1] = *reinterpret_cast<const f32x4*>(xrow + 8 * (kk + 1 < nk ? kk + 1 : kk));
         __builtin_amdgcn_sched_barrier(0);
-        mfma_step<NB>(acc, w0, x0);
+        mfma_step<NB>(acc, wr[kk % R0], xr[kk & 1]);
         __builtin_amdgcn_sched_barrier(0);
-      }
-      if (kk + 1 < nk) {
-        const f32x4* wp = w + (size_t)(ks + kk + 2) * (NB * 64);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) w0[nb] = wp[nb * 64];
-        x0 = *reinterpret_cast<const f32x4*>(xrow + 8 * (kk + 2 < nk ? kk + 2 : kk + 1));
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step<NB>(acc, w1, x1);
-        __builtin_amdgcn_sched_barrier(0);
-      } else if (kk < nk) {
-        // odd step count in this (last) slab: the next step's weights sit in slot 1; keep the
-        // invariant "next step is in w0" for a following slab (there is none after a partial slab)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) w0[nb] = w1[nb];
       }
     }
     ks += nk;
@@ -293,7 +285,16 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const EncArgs& a, int64_t
 }
 
 // ------------------------------------------------------------------------------------------
-template <bool VEC4, bool NORM>
+// DBG = true is the diagnostic build behind nlml_encoder_heads_fwd_debug: it also writes the
+// pre-Tanh activations and per-wave s_memtime stamps at the stage boundaries (read their SHARES,
+// not their length).  The production instantiations (DBG = false) contain neither.
+#define NLML_STAMP(i)                                                                              \
+  do {                                                                                             \
+    if (DBG && a.stamps && c.lane == 0)                                                            \
+      a.stamps[((size_t)blockIdx.x * 4 + wv) * 16 + (i)] = __builtin_amdgcn_s_memtime();         \
+  } while (0)
+
+template <bool VEC4, bool NORM, bool DBG>
 __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
@@ -311,33 +312,40 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
 
   {  // E0: F -> 1024, ReLU.  wave wv owns neurons 256*wv .. +255
     f32x16 acc[8];
+    NLML_STAMP(0);
     stage_e0<VEC4, NORM>(c, a, row0, tid, acc);
+    NLML_STAMP(1);
     job_store<8, ACT_RELU>(c, acc, lds + O_H1, S_H1, 256 * wv);
   }
   __syncthreads();
+  NLML_STAMP(2);
   {  // E1: 1024 -> 512, ReLU.  h2 overwrites h1 => barrier between the K loop and the store
     f32x16 acc[4];
     job_compute<4>(c, ST_E1, wv, acc, lds + O_H1, S_H1, 0, kStages[ST_E1].k8);
+    NLML_STAMP(3);
     __syncthreads();
     job_store<4, ACT_RELU>(c, acc, lds + O_H2, S_H2, 128 * wv);
   }
   __syncthreads();
+  NLML_STAMP(4);
   {  // E2: 512 -> 256, ReLU
     f32x16 acc[2];
     job_compute<2>(c, ST_E2, wv, acc, lds + O_H2, S_H2, 0, kStages[ST_E2].k8);
     job_store<2, ACT_RELU>(c, acc, lds + O_H3, S_H3, 64 * wv);
   }
   __syncthreads();
+  NLML_STAMP(5);
   {  // E3: 256 -> 128, ReLU
     f32x16 acc[1];
     job_compute<1>(c, ST_E3, wv, acc, lds + O_H3, S_H3, 0, kStages[ST_E3].k8);
     job_store<1, ACT_RELU>(c, acc, lds + O_H4, S_H4, 32 * wv);
   }
   __syncthreads();
+  NLML_STAMP(6);
   if (wv < 2) {  // E4: 128 -> 64, Tanh
     f32x16 acc[1];
     job_compute<1>(c, ST_E4, wv, acc, lds + O_H4, S_H4, 0, kStages[ST_E4].k8);
-    if (a.pre_tanh && row0 + c.f < a.B) {
+    if (DBG && a.pre_tanh && row0 + c.f < a.B) {
 #pragma unroll
       for (int q = 0; q < 16; ++q)
         a.pre_tanh[(row0 + c.f) * 64 + 32 * wv + (q & 3) + 8 * (q >> 2) + 4 * c.h] = acc[0][q];
@@ -345,6 +353,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
     job_store<1, ACT_TANH>(c, acc, lds + O_H5, S_H5, 32 * wv);
   }
   __syncthreads();
+  NLML_STAMP(7);
   if (wv == 0) {  // E5: 64 -> 9 (latent n = 3g+c on row 8g+c, other rows exact zeros)
     f32x16 acc[1];
     job_compute<1>(c, ST_E5, 0, acc, lds + O_H5, S_H5, 0, kStages[ST_E5].k8);
@@ -357,6 +366,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
       if (row0 + ff < a.B) a.latent[(row0 + ff) * NLML_LATENT + n] = lds[O_LAT + ff * S_LAT + 8 * (n / 3) + (n % 3)];
     }
   }
+  NLML_STAMP(8);
   // ---- heads (yaw, pitch, roll = g 0,1,2); jobs are (head, neuron block) pairs
 #pragma unroll 1
   for (int i = 0; i < 3; ++i) {  // H0: 3 -> 128 (K padded to 8 with zeros), ReLU
@@ -366,6 +376,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
     job_store<1, ACT_RELU>(c, acc, lds + O_HA, S_HA, 128 * g + 32 * nb);
   }
   __syncthreads();
+  NLML_STAMP(9);
 #pragma unroll 1
   for (int i = 0; i < 3; ++i) {  // H1: 128 -> 256, ReLU
     const int job = wv * 3 + i, g = job >> 2, p = job & 3;
@@ -374,6 +385,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
     job_store<2, ACT_RELU>(c, acc, lds + O_HB, S_HB, 256 * g + 64 * p);
   }
   __syncthreads();
+  NLML_STAMP(10);
 #pragma unroll 1
   for (int i = 0; i < 3; ++i) {  // H2: 256 -> 128, ReLU
     const int job = wv * 3 + i, g = job >> 2, nb = job & 3;
@@ -382,6 +394,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
     job_store<1, ACT_RELU>(c, acc, lds + O_HC, S_HC, 128 * g + 32 * nb);
   }
   __syncthreads();
+  NLML_STAMP(11);
 #pragma unroll 1
   for (int job = wv; job < 6; job += 4) {  // H3: 128 -> 64, ReLU
     const int g = job >> 1, nb = job & 1;
@@ -390,16 +403,18 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
     job_store<1, ACT_RELU>(c, acc, lds + O_HD, S_HD, 64 * g + 32 * nb);
   }
   __syncthreads();
+  NLML_STAMP(12);
   if (wv < 3) {  // H4: 64 -> 1; neuron on accumulator row 0 = register 0 of lanes 0..31
     f32x16 acc[1];
     job_compute<1>(c, ST_H4, wv, acc, lds + O_HD, S_HD, 64 * wv, kStages[ST_H4].k8);
     if (c.h == 0 && row0 + c.f < a.B) a.out[(row0 + c.f) * 3 + wv] = acc[0][0];
   }
+  NLML_STAMP(13);
 }
 
 int launch_encoder_heads_f32(const float* x, int64_t ldx, const float* raw, int normalize,
                              int64_t B, int F, const void* blob, float* out, float* latent,
-                             uint8_t* valid, float* pre_tanh, void* stream) {
+                             uint8_t* valid, float* pre_tanh, unsigned long long* stamps, void* stream) {
   if (B == 0) return 0;
   EncArgs a;
   a.B = B;
@@ -409,6 +424,8 @@ int launch_encoder_heads_f32(const float* x, int64_t ldx, const float* raw, int 
   a.latent = latent;
   a.valid = valid;
   a.pre_tanh = pre_tanh;
+  a.stamps = stamps;
+  const bool dbg = pre_tanh || stamps;
   a.norm = 0;
   if (raw) {  // raw landmarks [B,468,3]; without normalisation they ARE the feature rows
     a.x = raw;
@@ -421,12 +438,15 @@ int launch_encoder_heads_f32(const float* x, int64_t ldx, const float* raw, int 
   const bool vec4 = (F % 4 == 0) && (a.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
   const dim3 grid((unsigned)((B + TILE_FACES - 1) / TILE_FACES)), block(256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (a.norm) {
-    if (vec4) hipLaunchKernelGGL((encoder_heads_f32_kernel<true, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((encoder_heads_f32_kernel<false, true>), grid, block, 0, st, a);
+  if (dbg) {
+    if (a.norm || !vec4) return fail(NLML_E_BADARG, "debug build: features input, F % 4 == 0 only");
+    hipLaunchKernelGGL((encoder_heads_f32_kernel<true, false, true>), grid, block, 0, st, a);
+  } else if (a.norm) {
+    if (vec4) hipLaunchKernelGGL((encoder_heads_f32_kernel<true, true, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((encoder_heads_f32_kernel<false, true, false>), grid, block, 0, st, a);
   } else {
-    if (vec4) hipLaunchKernelGGL((encoder_heads_f32_kernel<true, false>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((encoder_heads_f32_kernel<false, false>), grid, block, 0, st, a);
+    if (vec4) hipLaunchKernelGGL((encoder_heads_f32_kernel<true, false, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((encoder_heads_f32_kernel<false, false, false>), grid, block, 0, st, a);
   }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));

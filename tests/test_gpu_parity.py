@@ -166,7 +166,7 @@ def test_errors_are_loud(head_sds, device):
     assert ops.encoder_heads_fwd(torch.zeros(0, 136, device=device), blob, 136).shape == (0, 3)
 
 
-@pytest.mark.parametrize("F,B,gain", [(1404, 257, 1.0), (1404, 64, 2.4), (136, 100, 2.4), (10, 33, 2.4)])
+@pytest.mark.parametrize("F,B,gain", [(1404, 257, 1.0), (1404, 64, 2.4), (136, 100, 2.4), (12, 33, 2.4)])
 def test_mfma_chain_bitexact_vs_c_oracle(F, B, gain, head_sds, device):
     """Everything before the Tanh is pure f32 fma: the MFMA chains must equal the C oracle's
     fmaf chains (same k order) bit for bit, whatever the weight gain.  After the Tanh (ocml vs

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Cycle-share breakdown of the fused kernel from the diagnostic build's s_memtime stamps (GPU box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from nlml_hpe_amd import ops, synth, weights
+dev = torch.device("cuda:0")
+F, B = 1404, 65536
+heads = weights.load_head_state_dicts("models")
+blob = torch.from_numpy(weights.pack_blob(synth.encoder_state_dict(F, 0), heads)).to(dev)
+x = torch.from_numpy(synth.features(B, F, 1)).to(dev)
+for _ in range(2):
+    out, lat, pre, st = ops.encoder_heads_fwd_debug(x, blob, F, want_stamps=True)
+torch.cuda.synchronize()
+st = st.cpu().numpy().astype(np.int64)            # [tiles, 4 waves, 16]
+names = ["E0 kloop", "E0 store+bar", "E1 kloop", "E1 bar+store+bar", "E2", "E3", "E4", "E5(+latent)", "H0", "H1", "H2", "H3", "H4"]
+d = np.diff(st[:, :, :14], axis=2).astype(np.float64)   # [tiles,4,13]
+tot = (st[:, :, 13] - st[:, :, 0]).astype(np.float64)
+print(f"tiles {st.shape[0]}  mean cycles/tile (wave avg) {tot.mean():,.0f}  min {tot.min():,.0f} max {tot.max():,.0f}")
+ideal = {"E0 kloop": 176*32*64, "E1 kloop": 128*16*64, "E2": 64*8*64, "E3": 32*4*64, "E4": 16*4*64, "E5(+latent)": 8*4*64,
+         "H0": 3*4*64, "H1": 3*16*8*64, "H2": 3*32*4*64, "H3": 2*16*4*64, "H4": 8*4*64}
+for i, n in enumerate(names):
+    m = d[:, :, i].mean()
+    extra = f"  ideal MFMA {ideal[n]:,}  ({ideal[n]/m*100:.0f}% busy)" if n in ideal else ""
+    print(f"{n:18s} {m:10,.0f} cyc  {m/tot.mean()*100:5.1f}%{extra}")
+print("per-wave totals:", [f"{tot[:, w].mean():,.0f}" for w in range(4)])
