@@ -98,7 +98,7 @@ int nlml_encoder_heads_fwd(const float* x, int64_t ldx, int64_t B, int F,
  *   pre_tanh f32[B,64] (or NULL): the Linear(128,64) outputs BEFORE the Tanh (Model_Builder.py:49-50);
  *            everything up to there is pure f32 fma, so it is compared bit for bit against the C
  *            oracle's fmaf chain (tests/test_gpu_parity.py);
- *   stamps   u64[ceil(B/32),4,16] (or NULL): per-wave s_memtime at the stage boundaries, for the
+ *   stamps   u64[ceil(B/64),4,16] (or NULL): per-wave s_memtime at the stage boundaries, for the
  *            cycle-share breakdown in profiles/ (never a run-time figure). */
 int nlml_encoder_heads_fwd_debug(const float* x, int64_t ldx, int64_t B, int F,
                                  const void* blob, size_t blob_bytes,

@@ -8,19 +8,26 @@
 // ~21 ATen launches per call in the reference; here ONE launch, activations never leave the CU.
 //
 // Shape of the computation on CDNA4 (gfx950):
-//   * one workgroup (4 waves, one per SIMD) = one tile of 32 faces through the WHOLE network;
+//   * one workgroup (4 waves, one per SIMD) = one tile of 64 faces through the WHOLE network;
 //   * every layer is D[neuron][face] += W[neuron][k] * act[k][face] on v_mfma_f32_32x32x2_f32
-//     (exact f32: a k-ordered fmaf chain), neurons on MFMA rows, the 32 faces on MFMA columns;
+//     (exact f32: a k-ordered fmaf chain), neurons on MFMA rows, faces on MFMA columns: the tile
+//     is two column blocks of 32 faces that SHARE every weight fragment;
 //   * waves split the NEURONS of a layer, so weights are private to a wave and stream
 //     global -> VGPR in the pre-packed fragment order of layout.h (one coalesced 1-KiB
-//     dwordx4 load per 32x8 weight block, L2/MALL resident, prefetched one K step ahead);
+//     dwordx4 load per 32x8 weight block = 8 MFMAs, L2/MALL resident, prefetched through a
+//     register ring several K steps ahead);
 //   * activations are shared by the 4 waves and live in LDS as [face][k] rows (stride 4*odd
 //     floats => conflict-free ds_read_b128 / ds_write_b128); each lane reads 16 B = the four
 //     k values of its face for the four MFMAs of a K step;
 //   * bias is the accumulator's initial value; ReLU/Tanh are applied on the way to LDS;
-//   * layer 0 streams x through a double-buffered 32x64 LDS slab (coalesced 256-B row reads),
+//   * layer 0's output for 64 faces (256 KB) does not fit the 160 KB LDS, so layers 0 and 1 are
+//     interleaved in two passes: pass A computes neurons 0..511 of layer 0 into LDS and layer 1
+//     accumulates over that K half; pass B does neurons 512..1023 in place and layer 1 finishes.
+//     Layer 1's 128 accumulator registers per lane stay live across pass B;
+//   * layer 0 streams x through a double-buffered 64x32 LDS slab (coalesced 128-B row segments),
 //     optionally applying the IPD normalisation (FeatureExtractor.py:30-66) in f64 on the way
-//     in, so normalised features never exist in HBM.
+//     in, so normalised features never exist in HBM;
+//   * E4, E5 and the heads (10 % of the FLOPs) run per 32-face block with the 32-face LDS images.
 #include <hip/hip_runtime.h>
 
 #include "../../include/nlml_hpe.h"
@@ -45,7 +52,7 @@ struct EncArgs {
   float* latent;        // [B,9] or null
   uint8_t* valid;       // [B] or null
   float* pre_tanh;      // [B,64] or null: E4 accumulators before the Tanh (test hook, DBG build only)
-  unsigned long long* stamps;  // [blocks,4 waves,16] s_memtime at stage boundaries (DBG build only)
+  unsigned long long* stamps;  // [tiles,4 waves,16] s_memtime at stage boundaries (DBG build only)
 };
 
 template <int ACT>
@@ -55,53 +62,61 @@ __device__ __forceinline__ float activate(float v) {
   return v;
 }
 
-template <int NB>
-__device__ __forceinline__ void load_bias(f32x16 (&acc)[NB], const f32x4* __restrict__ b, int h) {
+// acc[nb][fb]: neuron block nb x face block fb.  The bias depends on the neuron only.
+template <int NB, int NFB>
+__device__ __forceinline__ void load_bias(f32x16 (&acc)[NB][NFB], const f32x4* __restrict__ b, int h) {
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const f32x4* p = b + (nb * 2 + h) * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 v = p[q];
-      acc[nb][4 * q + 0] = v[0];
-      acc[nb][4 * q + 1] = v[1];
-      acc[nb][4 * q + 2] = v[2];
-      acc[nb][4 * q + 3] = v[3];
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) {
+        acc[nb][fb][4 * q + 0] = v[0];
+        acc[nb][fb][4 * q + 1] = v[1];
+        acc[nb][fb][4 * q + 2] = v[2];
+        acc[nb][fb][4 * q + 3] = v[3];
+      }
     }
   }
 }
 
-template <int NB>
-__device__ __forceinline__ void mfma_step(f32x16 (&acc)[NB], const f32x4 (&w)[NB], const f32x4 x) {
+template <int NB, int NFB>
+__device__ __forceinline__ void mfma_step(f32x16 (&acc)[NB][NFB], const f32x4 (&w)[NB], const f32x4 (&x)[NFB]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
-      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[nb][j], x[j], acc[nb], 0, 0, 0);
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb)
+        acc[nb][fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[nb][j], x[fb][j], acc[nb][fb], 0, 0, 0);
 }
 
 // Prefetch ring.  The compiler, left alone, sinks the weight loads of step s+1 below the MFMAs of
 // step s and then waits for them at once (34 % of wave cycles parked in s_waitcnt, profiles/r01):
-// so the loop is unrolled over a ring of R register buffers with the loads of step s+D (D = R-1)
-// pinned ABOVE the MFMAs of step s by sched_barrier.  R is chosen per NB so that D steps of MFMA
-// work (NB*256 cycles each) cover an L2 MISS (Infinity-Cache round trip, ~2 us under load: the first CU of an
-// XCD to touch a weight line pays it): NB 8 -> R 4 (6k cycles ahead), NB <= 4 -> R 8 (>= 7k / 3.5k / 1.8k cycles).
-template <int NB> struct Ring { static constexpr int R = NB >= 8 ? 4 : 8; };
+// so the K loops are unrolled over a ring of R register buffers with the loads of step s+D
+// (D = R-1) pinned ABOVE the MFMAs of step s by sched_barrier.  A K step is NB*NFB*256 cycles of
+// MFMA; D steps must cover an L2 miss (Infinity-Cache round trip, ~2 us under load).
+template <int NB, int NFB> struct Ring { static constexpr int R = (NB * NFB >= 8) ? 4 : 8; };
 
-// K loop with the input image resident in LDS.  `w` already points at this lane's first
-// fragment of the job, `in` at this lane's (face row, k-half) of the input image.  Loads run up to
-// D steps past the job's end (next job / tail pad of the blob: harmless); LDS reads are clamped.
-template <int NB>
-__device__ __forceinline__ void kloop_lds(f32x16 (&acc)[NB], const f32x4* __restrict__ w,
-                                          const float* in, int k8) {
-  constexpr int R = Ring<NB>::R, D = R - 1;
+// K loop with the input image resident in LDS.  `w` points at this lane's first fragment of the
+// job's FIRST K step to run, `in` at this lane's (face row of block 0, k-half) of the input image
+// at that step; face block fb is fb_stride floats further.  Weight loads run up to D steps past
+// the last step (next job / tail pad of the blob: harmless); LDS reads are clamped.
+template <int NB, int NFB>
+__device__ __forceinline__ void kloop_lds(f32x16 (&acc)[NB][NFB], const f32x4* __restrict__ w,
+                                          const float* in, int fb_stride, int k8) {
+  constexpr int R = Ring<NB, NFB>::R, D = R - 1;
   f32x4 wr[R][NB];
-  f32x4 xr[R];
+  f32x4 xr[R][NFB];
 #pragma unroll
   for (int d = 0; d < D; ++d) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) wr[d][nb] = w[(d * NB + nb) * 64];
-    xr[d] = *reinterpret_cast<const f32x4*>(in + 8 * (d < k8 ? d : k8 - 1));
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+      xr[d][fb] = *reinterpret_cast<const f32x4*>(in + fb * fb_stride + 8 * (d < k8 ? d : k8 - 1));
   }
   for (int s0 = 0; s0 < k8; s0 += R) {
 #pragma unroll
@@ -112,9 +127,11 @@ __device__ __forceinline__ void kloop_lds(f32x16 (&acc)[NB], const f32x4* __rest
         const f32x4* wp = w + (size_t)sp * (NB * 64);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) wr[(r + D) % R][nb] = wp[nb * 64];
-        xr[(r + D) % R] = *reinterpret_cast<const f32x4*>(in + 8 * (sp < k8 ? sp : k8 - 1));
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb)
+          xr[(r + D) % R][fb] = *reinterpret_cast<const f32x4*>(in + fb * fb_stride + 8 * (sp < k8 ? sp : k8 - 1));
         __builtin_amdgcn_sched_barrier(0);
-        mfma_step<NB>(acc, wr[r], xr[r]);
+        mfma_step<NB, NFB>(acc, wr[r], xr[r]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -122,20 +139,22 @@ __device__ __forceinline__ void kloop_lds(f32x16 (&acc)[NB], const f32x4* __rest
 }
 
 // Accumulators -> activation -> LDS image [face][neuron]; `out` points at this lane's
-// (face row, first neuron of the job + 4*h).
-template <int NB, int ACT>
-__device__ __forceinline__ void store_lds(const f32x16 (&acc)[NB], float* out) {
+// (face row of block 0, first neuron of the job + 4*h).
+template <int NB, int NFB, int ACT>
+__device__ __forceinline__ void store_lds(const f32x16 (&acc)[NB][NFB], float* out, int fb_stride) {
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 v;
-      v[0] = activate<ACT>(acc[nb][4 * q + 0]);
-      v[1] = activate<ACT>(acc[nb][4 * q + 1]);
-      v[2] = activate<ACT>(acc[nb][4 * q + 2]);
-      v[3] = activate<ACT>(acc[nb][4 * q + 3]);
-      *reinterpret_cast<f32x4*>(out + 32 * nb + 8 * q) = v;
-    }
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+        v[0] = activate<ACT>(acc[nb][fb][4 * q + 0]);
+        v[1] = activate<ACT>(acc[nb][fb][4 * q + 1]);
+        v[2] = activate<ACT>(acc[nb][fb][4 * q + 2]);
+        v[3] = activate<ACT>(acc[nb][fb][4 * q + 3]);
+        *reinterpret_cast<f32x4*>(out + fb * fb_stride + 32 * nb + 8 * q) = v;
+      }
 }
 
 struct Ctx {
@@ -145,102 +164,117 @@ struct Ctx {
   int lane, f, h, wv;
 };
 
-// One job whose input is an LDS image: bias init + K loop.  Returns with acc ready.
-template <int NB>
-__device__ __forceinline__ void job_compute(const Ctx& c, int stage, int job, f32x16 (&acc)[NB],
-                                            const float* in_img, int in_stride, int in_col, int k8) {
-  load_bias<NB>(acc, c.blob4 + c.hdr->b_off[stage] + job * (NB * 8), c.h);
+// Bias init + K loop of one job over an LDS image.  face0: first face row (0 or 32) of the job.
+template <int NB, int NFB>
+__device__ __forceinline__ void job_compute(const Ctx& c, int stage, int job, f32x16 (&acc)[NB][NFB],
+                                            const float* in_img, int in_stride, int in_col, int face0, int k8) {
+  load_bias<NB, NFB>(acc, c.blob4 + c.hdr->b_off[stage] + job * (NB * 8), c.h);
   const f32x4* w = c.blob4 + c.hdr->w_off[stage] + (size_t)job * c.hdr->job_w16[stage] + c.lane;
-  kloop_lds<NB>(acc, w, in_img + c.f * in_stride + in_col + 4 * c.h, k8);
+  kloop_lds<NB, NFB>(acc, w, in_img + (face0 + c.f) * in_stride + in_col + 4 * c.h, 32 * in_stride, k8);
 }
 
-template <int NB, int ACT>
-__device__ __forceinline__ void job_store(const Ctx& c, const f32x16 (&acc)[NB], float* out_img,
-                                          int out_stride, int out_col) {
-  store_lds<NB, ACT>(acc, out_img + c.f * out_stride + out_col + 4 * c.h);
+template <int NB, int NFB, int ACT>
+__device__ __forceinline__ void job_store(const Ctx& c, const f32x16 (&acc)[NB][NFB], float* out_img,
+                                          int out_stride, int out_col, int face0) {
+  store_lds<NB, NFB, ACT>(acc, out_img + (face0 + c.f) * out_stride + out_col + 4 * c.h, 32 * out_stride);
 }
 
 // ------------------------------------------------------------------------------------------
-// Stage E0: x[32,F] streamed through LDS slabs of 64 columns.
-template <bool VEC4, bool NORM>
-__device__ __forceinline__ void stage_e0(const Ctx& c, const EncArgs& a, int64_t row0, int tid,
-                                         f32x16 (&acc)[8]) {
-  constexpr int NB = 8;
-  float* xs = c.lds + O_XS;
-  const int F = a.F;
-  const int k8_total = (int)c.hdr->k8_e0;
-  const int nslab = (F + 63) >> 6;
+// Layer 0, one pass: x[64,F] streamed through LDS slabs of 32 columns; this wave computes the 128
+// neurons of job `job` (4 blocks) for both face blocks.
+struct E0Stager {
+  const float *p0, *p1;       // this thread's two rows (srow, srow + 32)
+  double ref0[3], ref1[3], ipd0, ipd1;
+  int srow, scol;
+  bool live0, live1, nz0, nz1;
+};
 
-  // staging role of this thread: rows srow and srow+16, columns scol..scol+3 of each slab
-  const int srow = tid >> 4, scol = (tid & 15) * 4;
-  int64_t r0 = row0 + srow, r1 = row0 + srow + 16;
-  const bool live0 = r0 < a.B, live1 = r1 < a.B;
-  r0 = live0 ? r0 : a.B - 1;
-  r1 = live1 ? r1 : a.B - 1;
-  const float* p0 = a.x + r0 * a.ldx;
-  const float* p1 = a.x + r1 * a.ldx;
-
-  // IPD normalisation constants of the two rows (FeatureExtractor.py:38-48,85-86), f64
-  double ref0[3] = {0, 0, 0}, ref1[3] = {0, 0, 0}, ipd0 = 1.0, ipd1 = 1.0;
-  if (NORM) {
+template <bool NORM>
+__device__ __forceinline__ void e0_stager_init(E0Stager& g, const EncArgs& a, int64_t row0, int tid) {
+  g.srow = tid >> 3;
+  g.scol = (tid & 7) * 4;
+  int64_t r0 = row0 + g.srow, r1 = row0 + g.srow + 32;
+  g.live0 = r0 < a.B;
+  g.live1 = r1 < a.B;
+  r0 = g.live0 ? r0 : a.B - 1;
+  r1 = g.live1 ? r1 : a.B - 1;
+  g.p0 = a.x + r0 * a.ldx;
+  g.p1 = a.x + r1 * a.ldx;
+  g.nz0 = g.nz1 = false;
+  g.ipd0 = g.ipd1 = 1.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g.ref0[k] = g.ref1[k] = 0.0;
+  if (NORM) {  // IPD normalisation constants of the two rows (FeatureExtractor.py:38-48,85-86), f64
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-      const float* p = rr ? p1 : p0;
-      double* ref = rr ? ref1 : ref0;
+      const float* p = rr ? g.p1 : g.p0;
+      double* ref = rr ? g.ref1 : g.ref0;
       ref[0] = (double)p[3]; ref[1] = (double)p[4]; ref[2] = (double)p[5];       // landmark 1
       const double dx = (double)p[99] - (double)p[789];                           // 33 vs 263
       const double dy = (double)p[100] - (double)p[790];
       const double dz = (double)p[101] - (double)p[791];
       double d = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));  // == np.linalg.norm (sqrt of an fma-chained ddot)
       if (d == 0.0) d = 1e-6;
-      if (rr) ipd1 = d; else ipd0 = d;
+      if (rr) g.ipd1 = d; else g.ipd0 = d;
     }
   }
+}
+
+template <bool VEC4, bool NORM>
+__device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0Stager& g, int job,
+                                              f32x16 (&acc)[4][2]) {
+  constexpr int NB = 4, NFB = 2;
+  float* xs = c.lds + O_XS;
+  const int F = a.F;
+  const int k8_total = (int)c.hdr->k8_e0;
+  const int nslab = (F + XS_COLS - 1) / XS_COLS;
 
   f32x4 s0, s1;
-  bool nz0 = false, nz1 = false;
   auto gload = [&](int s) {
-    const int k = s * 64 + scol;
+    const int k = s * XS_COLS + g.scol;
     if (VEC4) {
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      s0 = (k < F) ? *reinterpret_cast<const f32x4*>(p0 + k) : z;
-      s1 = (k < F) ? *reinterpret_cast<const f32x4*>(p1 + k) : z;
+      s0 = (k < F) ? *reinterpret_cast<const f32x4*>(g.p0 + k) : z;
+      s1 = (k < F) ? *reinterpret_cast<const f32x4*>(g.p1 + k) : z;
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        s0[e] = (k + e < F) ? p0[k + e] : 0.f;
-        s1[e] = (k + e < F) ? p1[k + e] : 0.f;
+        s0[e] = (k + e < F) ? g.p0[k + e] : 0.f;
+        s1[e] = (k + e < F) ? g.p1[k + e] : 0.f;
       }
     }
   };
   auto lwrite = [&](int s, int buf) {
     if (NORM) {
-      const int k = s * 64 + scol;
+      const int k = s * XS_COLS + g.scol;
       int cidx = k % 3;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (k + e < F) {
-          s0[e] = (float)(((double)s0[e] - ref0[cidx]) / ipd0);
-          s1[e] = (float)(((double)s1[e] - ref1[cidx]) / ipd1);
+        if (k + e < F) {  // explicit selects: a runtime-indexed array would live in scratch
+          const double r0 = cidx == 0 ? g.ref0[0] : (cidx == 1 ? g.ref0[1] : g.ref0[2]);
+          const double r1 = cidx == 0 ? g.ref1[0] : (cidx == 1 ? g.ref1[1] : g.ref1[2]);
+          s0[e] = (float)(((double)s0[e] - r0) / g.ipd0);
+          s1[e] = (float)(((double)s1[e] - r1) / g.ipd1);
         }
         cidx = (cidx == 2) ? 0 : cidx + 1;
       }
     }
-    nz0 |= (s0[0] != 0.f) | (s0[1] != 0.f) | (s0[2] != 0.f) | (s0[3] != 0.f);
-    nz1 |= (s1[0] != 0.f) | (s1[1] != 0.f) | (s1[2] != 0.f) | (s1[3] != 0.f);
-    float* d = xs + buf * (32 * S_XS);
-    *reinterpret_cast<f32x4*>(d + srow * S_XS + scol) = s0;
-    *reinterpret_cast<f32x4*>(d + (srow + 16) * S_XS + scol) = s1;
+    g.nz0 |= (s0[0] != 0.f) | (s0[1] != 0.f) | (s0[2] != 0.f) | (s0[3] != 0.f);
+    g.nz1 |= (s1[0] != 0.f) | (s1[1] != 0.f) | (s1[2] != 0.f) | (s1[3] != 0.f);
+    float* d = xs + buf * (64 * S_XS);
+    *reinterpret_cast<f32x4*>(d + g.srow * S_XS + g.scol) = s0;
+    *reinterpret_cast<f32x4*>(d + (g.srow + 32) * S_XS + g.scol) = s1;
   };
 
-  load_bias<NB>(acc, c.blob4 + c.hdr->b_off[ST_E0] + c.wv * (NB * 8), c.h);
-  const f32x4* w = c.blob4 + c.hdr->w_off[ST_E0] + (size_t)c.wv * c.hdr->job_w16[ST_E0] + c.lane;
+  load_bias<NB, NFB>(acc, c.blob4 + c.hdr->b_off[ST_E0] + job * (NB * 8), c.h);
+  const f32x4* w = c.blob4 + c.hdr->w_off[ST_E0] + (size_t)job * c.hdr->job_w16[ST_E0] + c.lane;
 
   gload(0);
   lwrite(0, 0);
-  // weight ring of R0 = 4 slots: K step ks lives in slot ks % 4; a full slab holds 8 steps, so the slot
+  // weight ring of R0 = 4 slots: K step ks lives in slot ks % 4; a full slab holds 4 steps, so the slot
   // of every step is static inside the unrolled slab body.  x ring of 2 inside the slab.
-  constexpr int R0 = Ring<NB>::R, D0 = R0 - 1;
+  constexpr int R0 = 4, D0 = R0 - 1;
+  static_assert(XS_STEPS == R0, "slab steps == ring slots keeps the slot index static");
   f32x4 wr[R0][NB];
 #pragma unroll
   for (int d = 0; d < D0; ++d)
@@ -252,35 +286,30 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const EncArgs& a, int64_t
   for (int s = 0; s < nslab; ++s) {
     const bool more = s + 1 < nslab;
     if (more) gload(s + 1);
-    const float* xrow = xs + (s & 1) * (32 * S_XS) + c.f * S_XS + 4 * c.h;
+    const float* xrow = xs + (s & 1) * (64 * S_XS) + c.f * S_XS + 4 * c.h;
     int nk = k8_total - ks;
-    nk = nk > 8 ? 8 : nk;
-    f32x4 xr[2];
-    xr[0] = *reinterpret_cast<const f32x4*>(xrow);
+    nk = nk > XS_STEPS ? XS_STEPS : nk;
+    f32x4 xr[2][NFB];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
+    for (int fb = 0; fb < NFB; ++fb) xr[0][fb] = *reinterpret_cast<const f32x4*>(xrow + fb * (32 * S_XS));
+#pragma unroll
+    for (int kk = 0; kk < XS_STEPS; ++kk) {
       if (kk < nk) {
         const f32x4* wp = w + (size_t)(ks + kk + D0) * (NB * 64);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) wr[(kk + D0) % R0][nb] = wp[nb * 64];
-        xr[(kk + 1) & 1] = *reinterpret_cast<const f32x4*>(xrow + 8 * (kk + 1 < nk ? kk + 1 : kk));
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb)
+          xr[(kk + 1) & 1][fb] =
+              *reinterpret_cast<const f32x4*>(xrow + fb * (32 * S_XS) + 8 * (kk + 1 < nk ? kk + 1 : kk));
         __builtin_amdgcn_sched_barrier(0);
-        mfma_step<NB>(acc, wr[kk % R0], xr[kk & 1]);
+        mfma_step<NB, NFB>(acc, wr[kk % R0], xr[kk & 1]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     ks += nk;
     if (more) lwrite(s + 1, (s + 1) & 1);
     __syncthreads();
-  }
-
-  if (a.valid) {  // all-zero feature row == "no face" (FeatureExtractor.py:105-106)
-    const unsigned long long m0 = __ballot(nz0), m1 = __ballot(nz1);
-    if ((tid & 15) == 0) {
-      const int sh = c.lane & 48;
-      if (live0) a.valid[row0 + srow] = ((m0 >> sh) & 0xFFFFull) ? 1 : 0;
-      if (live1) a.valid[row0 + srow + 16] = ((m1 >> sh) & 0xFFFFull) ? 1 : 0;
-    }
   }
 }
 
@@ -310,104 +339,124 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
   const int wv = c.wv;
   const int64_t row0 = (int64_t)blockIdx.x * TILE_FACES;
 
-  {  // E0: F -> 1024, ReLU.  wave wv owns neurons 256*wv .. +255
-    f32x16 acc[8];
+  {  // ---- layers 0 and 1 interleaved in two passes over x (see header)
+    E0Stager g;
+    e0_stager_init<NORM>(g, a, row0, tid);
+    f32x16 acc1[4][2];  // layer 1: neurons 128*wv .. +127, both face blocks; live across pass B
+    load_bias<4, 2>(acc1, c.blob4 + c.hdr->b_off[ST_E1] + wv * (4 * 8), c.h);
+    const f32x4* w1 = c.blob4 + c.hdr->w_off[ST_E1] + (size_t)wv * c.hdr->job_w16[ST_E1] + c.lane;
     NLML_STAMP(0);
-    stage_e0<VEC4, NORM>(c, a, row0, tid, acc);
-    NLML_STAMP(1);
-    job_store<8, ACT_RELU>(c, acc, lds + O_H1, S_H1, 256 * wv);
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      {  // E0 half: F -> neurons 512*pass + 128*wv .. +127, ReLU
+        f32x16 acc0[4][2];
+        stage_e0_pass<VEC4, NORM>(c, a, g, pass * 4 + wv, acc0);
+        NLML_STAMP(1 + 4 * pass);
+        // the previous pass's h1 half was fully consumed before this pass's slab barriers
+        job_store<4, 2, ACT_RELU>(c, acc0, lds + O_H1H, S_H1H, 128 * wv, 0);
+      }
+      __syncthreads();
+      NLML_STAMP(2 + 4 * pass);
+      // E1 over this K half: k = 512*pass .. +511  (64 steps of 8)
+      kloop_lds<4, 2>(acc1, w1 + (size_t)pass * 64 * (4 * 64), lds + O_H1H + c.f * S_H1H + 4 * c.h, 32 * S_H1H, 64);
+      NLML_STAMP(3 + 4 * pass);
+      __syncthreads();  // all waves done reading this h1 half before it is overwritten
+      NLML_STAMP(4 + 4 * pass);
+    }
+    if (a.valid) {  // all-zero feature row == "no face" (FeatureExtractor.py:105-106)
+      const unsigned long long m0 = __ballot(g.nz0), m1 = __ballot(g.nz1);
+      if ((tid & 7) == 0) {
+        const int sh = c.lane & 56;
+        if (g.live0) a.valid[row0 + g.srow] = ((m0 >> sh) & 0xFFull) ? 1 : 0;
+        if (g.live1) a.valid[row0 + g.srow + 32] = ((m1 >> sh) & 0xFFull) ? 1 : 0;
+      }
+    }
+    job_store<4, 2, ACT_RELU>(c, acc1, lds + O_H2, S_H2, 128 * wv, 0);
   }
   __syncthreads();
-  NLML_STAMP(2);
-  {  // E1: 1024 -> 512, ReLU.  h2 overwrites h1 => barrier between the K loop and the store
-    f32x16 acc[4];
-    job_compute<4>(c, ST_E1, wv, acc, lds + O_H1, S_H1, 0, kStages[ST_E1].k8);
-    NLML_STAMP(3);
+  NLML_STAMP(9);
+  {  // E2: 512 -> 256, ReLU.  h3 overwrites h2 => barrier between the K loop and the store
+    f32x16 acc[2][2];
+    job_compute<2, 2>(c, ST_E2, wv, acc, lds + O_H2, S_H2, 0, 0, kStages[ST_E2].k8);
     __syncthreads();
-    job_store<4, ACT_RELU>(c, acc, lds + O_H2, S_H2, 128 * wv);
+    job_store<2, 2, ACT_RELU>(c, acc, lds + O_H3, S_H3, 64 * wv, 0);
   }
   __syncthreads();
-  NLML_STAMP(4);
-  {  // E2: 512 -> 256, ReLU
-    f32x16 acc[2];
-    job_compute<2>(c, ST_E2, wv, acc, lds + O_H2, S_H2, 0, kStages[ST_E2].k8);
-    job_store<2, ACT_RELU>(c, acc, lds + O_H3, S_H3, 64 * wv);
-  }
-  __syncthreads();
-  NLML_STAMP(5);
+  NLML_STAMP(10);
   {  // E3: 256 -> 128, ReLU
-    f32x16 acc[1];
-    job_compute<1>(c, ST_E3, wv, acc, lds + O_H3, S_H3, 0, kStages[ST_E3].k8);
-    job_store<1, ACT_RELU>(c, acc, lds + O_H4, S_H4, 32 * wv);
+    f32x16 acc[1][2];
+    job_compute<1, 2>(c, ST_E3, wv, acc, lds + O_H3, S_H3, 0, 0, kStages[ST_E3].k8);
+    job_store<1, 2, ACT_RELU>(c, acc, lds + O_H4, S_H4, 32 * wv, 0);
   }
   __syncthreads();
-  NLML_STAMP(6);
-  if (wv < 2) {  // E4: 128 -> 64, Tanh
-    f32x16 acc[1];
-    job_compute<1>(c, ST_E4, wv, acc, lds + O_H4, S_H4, 0, kStages[ST_E4].k8);
-    if (DBG && a.pre_tanh && row0 + c.f < a.B) {
+  NLML_STAMP(11);
+  {  // E4: 128 -> 64, Tanh.  4 single-face-block jobs: neuron block wv&1, face block wv>>1
+    const int nb = wv & 1, face0 = 32 * (wv >> 1);
+    f32x16 acc[1][1];
+    job_compute<1, 1>(c, ST_E4, nb, acc, lds + O_H4, S_H4, 0, face0, kStages[ST_E4].k8);
+    if (DBG && a.pre_tanh && row0 + face0 + c.f < a.B) {
 #pragma unroll
       for (int q = 0; q < 16; ++q)
-        a.pre_tanh[(row0 + c.f) * 64 + 32 * wv + (q & 3) + 8 * (q >> 2) + 4 * c.h] = acc[0][q];
+        a.pre_tanh[(row0 + face0 + c.f) * 64 + 32 * nb + (q & 3) + 8 * (q >> 2) + 4 * c.h] = acc[0][0][q];
     }
-    job_store<1, ACT_TANH>(c, acc, lds + O_H5, S_H5, 32 * wv);
+    job_store<1, 1, ACT_TANH>(c, acc, lds + O_H5, S_H5, 32 * nb, face0);
   }
   __syncthreads();
-  NLML_STAMP(7);
-  if (wv == 0) {  // E5: 64 -> 9 (latent n = 3g+c on row 8g+c, other rows exact zeros)
-    f32x16 acc[1];
-    job_compute<1>(c, ST_E5, 0, acc, lds + O_H5, S_H5, 0, kStages[ST_E5].k8);
-    job_store<1, ACT_NONE>(c, acc, lds + O_LAT, S_LAT, 0);
+  if (wv < 2) {  // E5: 64 -> 9 (latent n = 3g+c on row 8g+c, other rows exact zeros); face block wv
+    f32x16 acc[1][1];
+    job_compute<1, 1>(c, ST_E5, 0, acc, lds + O_H5, S_H5, 0, 32 * wv, kStages[ST_E5].k8);
+    job_store<1, 1, ACT_NONE>(c, acc, lds + O_LAT, S_LAT, 0, 32 * wv);
   }
   __syncthreads();
+  NLML_STAMP(12);
   if (a.latent) {  // optional: the encoder output before the split (Model_Builder.py:58)
     for (int i = tid; i < TILE_FACES * NLML_LATENT; i += 256) {
       const int ff = i / NLML_LATENT, n = i % NLML_LATENT;
       if (row0 + ff < a.B) a.latent[(row0 + ff) * NLML_LATENT + n] = lds[O_LAT + ff * S_LAT + 8 * (n / 3) + (n % 3)];
     }
   }
-  NLML_STAMP(8);
-  // ---- heads (yaw, pitch, roll = g 0,1,2); jobs are (head, neuron block) pairs
+  // ---- heads (yaw, pitch, roll = g 0,1,2), one 32-face block at a time; jobs are (head, neuron block)
 #pragma unroll 1
-  for (int i = 0; i < 3; ++i) {  // H0: 3 -> 128 (K padded to 8 with zeros), ReLU
-    const int job = wv * 3 + i, g = job >> 2, nb = job & 3;
-    f32x16 acc[1];
-    job_compute<1>(c, ST_H0, job, acc, lds + O_LAT, S_LAT, 8 * g, 1);
-    job_store<1, ACT_RELU>(c, acc, lds + O_HA, S_HA, 128 * g + 32 * nb);
-  }
-  __syncthreads();
-  NLML_STAMP(9);
+  for (int fb = 0; fb < 2; ++fb) {
+    const int face0 = 32 * fb;
 #pragma unroll 1
-  for (int i = 0; i < 3; ++i) {  // H1: 128 -> 256, ReLU
-    const int job = wv * 3 + i, g = job >> 2, p = job & 3;
-    f32x16 acc[2];
-    job_compute<2>(c, ST_H1, job, acc, lds + O_HA, S_HA, 128 * g, kStages[ST_H1].k8);
-    job_store<2, ACT_RELU>(c, acc, lds + O_HB, S_HB, 256 * g + 64 * p);
-  }
-  __syncthreads();
-  NLML_STAMP(10);
+    for (int i = 0; i < 3; ++i) {  // H0: 3 -> 128 (K padded to 8 with zeros), ReLU
+      const int job = wv * 3 + i, g = job >> 2, nb = job & 3;
+      f32x16 acc[1][1];
+      job_compute<1, 1>(c, ST_H0, job, acc, lds + O_LAT, S_LAT, 8 * g, face0, 1);
+      job_store<1, 1, ACT_RELU>(c, acc, lds + O_HA, S_HA, 128 * g + 32 * nb, 0);
+    }
+    __syncthreads();
 #pragma unroll 1
-  for (int i = 0; i < 3; ++i) {  // H2: 256 -> 128, ReLU
-    const int job = wv * 3 + i, g = job >> 2, nb = job & 3;
-    f32x16 acc[1];
-    job_compute<1>(c, ST_H2, job, acc, lds + O_HB, S_HB, 256 * g, kStages[ST_H2].k8);
-    job_store<1, ACT_RELU>(c, acc, lds + O_HC, S_HC, 128 * g + 32 * nb);
-  }
-  __syncthreads();
-  NLML_STAMP(11);
+    for (int i = 0; i < 3; ++i) {  // H1: 128 -> 256, ReLU
+      const int job = wv * 3 + i, g = job >> 2, p = job & 3;
+      f32x16 acc[2][1];
+      job_compute<2, 1>(c, ST_H1, job, acc, lds + O_HA, S_HA, 128 * g, 0, kStages[ST_H1].k8);
+      job_store<2, 1, ACT_RELU>(c, acc, lds + O_HB, S_HB, 256 * g + 64 * p, 0);
+    }
+    __syncthreads();
 #pragma unroll 1
-  for (int job = wv; job < 6; job += 4) {  // H3: 128 -> 64, ReLU
-    const int g = job >> 1, nb = job & 1;
-    f32x16 acc[1];
-    job_compute<1>(c, ST_H3, job, acc, lds + O_HC, S_HC, 128 * g, kStages[ST_H3].k8);
-    job_store<1, ACT_RELU>(c, acc, lds + O_HD, S_HD, 64 * g + 32 * nb);
-  }
-  __syncthreads();
-  NLML_STAMP(12);
-  if (wv < 3) {  // H4: 64 -> 1; neuron on accumulator row 0 = register 0 of lanes 0..31
-    f32x16 acc[1];
-    job_compute<1>(c, ST_H4, wv, acc, lds + O_HD, S_HD, 64 * wv, kStages[ST_H4].k8);
-    if (c.h == 0 && row0 + c.f < a.B) a.out[(row0 + c.f) * 3 + wv] = acc[0][0];
+    for (int i = 0; i < 3; ++i) {  // H2: 256 -> 128, ReLU
+      const int job = wv * 3 + i, g = job >> 2, nb = job & 3;
+      f32x16 acc[1][1];
+      job_compute<1, 1>(c, ST_H2, job, acc, lds + O_HB, S_HB, 256 * g, 0, kStages[ST_H2].k8);
+      job_store<1, 1, ACT_RELU>(c, acc, lds + O_HC, S_HC, 128 * g + 32 * nb, 0);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int job = wv; job < 6; job += 4) {  // H3: 128 -> 64, ReLU
+      const int g = job >> 1, nb = job & 1;
+      f32x16 acc[1][1];
+      job_compute<1, 1>(c, ST_H3, job, acc, lds + O_HC, S_HC, 128 * g, 0, kStages[ST_H3].k8);
+      job_store<1, 1, ACT_RELU>(c, acc, lds + O_HD, S_HD, 64 * g + 32 * nb, 0);
+    }
+    __syncthreads();
+    if (wv < 3) {  // H4: 64 -> 1; neuron on accumulator row 0 = register 0 of lanes 0..31
+      f32x16 acc[1][1];
+      job_compute<1, 1>(c, ST_H4, wv, acc, lds + O_HD, S_HD, 64 * wv, 0, kStages[ST_H4].k8);
+      if (c.h == 0 && row0 + face0 + c.f < a.B) a.out[(row0 + face0 + c.f) * 3 + wv] = acc[0][0][0];
+    }
+    __syncthreads();  // hd / ha regions are reused by the next face block
   }
   NLML_STAMP(13);
 }

@@ -4,7 +4,7 @@
 //
 // The network (NLML_HPE_Model_Builder.py:33-53,76-92) is cut into 11 STAGES; each stage is a
 // list of JOBS; one job = NB blocks of 32 output neurons that share one input slice, computed
-// by ONE wave for all 32 faces of the tile with v_mfma_f32_32x32x2_f32:
+// by ONE wave for the faces of the tile with v_mfma_f32_32x32x2_f32:
 //
 //     D[n][face] += A[n][k] * B[k][face],   A = weights (rows), B = activations (columns)
 //
@@ -21,6 +21,10 @@
 //
 //     bias[job][nb][h][q] : float, q < 16
 //
+// A tile is 64 faces = two MFMA column blocks ("face blocks") that share every weight fragment
+// (each 1-KiB weight load feeds 8 MFMAs), which halves the weight stream per FLOP against a
+// 32-face tile -- the stream, not the matrix pipe, was the limit at 32 (profiles/).
+//
 // Blob = header (256 B) | stage 0 weights | stage 0 bias | stage 1 ... | tail pad.
 // Header words (uint32): see Header below.  All offsets are in units of 16 bytes from blob start.
 #pragma once
@@ -29,9 +33,9 @@
 namespace nlml {
 
 constexpr uint32_t BLOB_MAGIC = 0x4E4C4D4Cu;  // "NLML"
-constexpr uint32_t BLOB_VERSION = 1;
+constexpr uint32_t BLOB_VERSION = 2;
 
-constexpr int TILE_FACES = 32;   // faces per workgroup tile = MFMA N
+constexpr int TILE_FACES = 64;   // faces per workgroup tile = 2 MFMA column blocks of 32
 constexpr int NUM_WAVES = 4;
 constexpr int NUM_STAGES = 11;   // E0..E5, H0..H4
 
@@ -48,7 +52,7 @@ struct StageDesc {
 // Static part of the stage table (E0's K/k8 depend on F).
 //                                   nb jobs   K   k8
 constexpr StageDesc kStages[NUM_STAGES] = {
-    /*E0  F   ->1024 relu*/ {8, 4, 0, 0},
+    /*E0  F   ->1024 relu*/ {4, 8, 0, 0},   // jobs 0-3: neurons 0..511 (pass A), 4-7: 512..1023 (pass B)
     /*E1 1024-> 512 relu*/ {4, 4, 1024, 128},
     /*E2  512-> 256 relu*/ {2, 4, 512, 64},
     /*E3  256-> 128 relu*/ {1, 4, 256, 32},
@@ -75,34 +79,39 @@ struct Header {
 };
 static_assert(sizeof(Header) == 256, "header is 256 bytes");
 
-// LDS activation images: [32 faces][stride] f32, stride = 4*odd => conflict-free ds_read_b128
+// LDS activation images: [faces][stride] f32, stride = 4*odd => conflict-free ds_read_b128
 // (16-lane groups) and ds_write_b128 (8-lane groups); see DESIGN.md "LDS images".
-constexpr int S_H1 = 1028;  // E0 out 1024
+// The encoder trunk (E0..E3) runs on all 64 faces; E4, E5 and the heads run per 32-face block.
+constexpr int S_H1H = 516;  // one HALF of E0's output: 512 neurons (pass A or pass B)
 constexpr int S_H2 = 516;   // E1 out 512
 constexpr int S_H3 = 260;   // E2 out 256
 constexpr int S_H4 = 132;   // E3 out 128
 constexpr int S_H5 = 68;    // E4 out 64 (tanh)
 constexpr int S_LAT = 36;   // E5 out: latent, head g at columns 8g..8g+2, rest exact zeros
-constexpr int S_HA = 388;   // H0 out 3 x 128
-constexpr int S_HB = 772;   // H1 out 3 x 256
-constexpr int S_HC = 388;   // H2 out 3 x 128
-constexpr int S_HD = 196;   // H3 out 3 x 64
-constexpr int S_XS = 68;    // E0 input slab: 64 columns of x (+4 pad)
+constexpr int S_HA = 388;   // H0 out 3 x 128   (32 faces)
+constexpr int S_HB = 772;   // H1 out 3 x 256   (32 faces)
+constexpr int S_HC = 388;   // H2 out 3 x 128   (32 faces)
+constexpr int S_HD = 196;   // H3 out 3 x 64    (32 faces)
+constexpr int S_XS = 36;    // E0 input slab: 32 columns of x (+4 pad)
+constexpr int XS_COLS = 32;
+constexpr int XS_STEPS = XS_COLS / 8;
 
 // LDS offsets (floats).  Lifetimes are sequential; see DESIGN.md for the overlap argument.
-constexpr int O_H1 = 0;                          // 32*1028 = 32896
-constexpr int O_XS = 32 * S_H1;                  // 2 slabs x 32*68 = 4352  -> ends 37248
-constexpr int O_H2 = 0;                          // written after E1's K loop (barrier)
-constexpr int O_H3 = 32 * S_H2;                  // 16512 .. 24832
-constexpr int O_H4 = O_H3 + 32 * S_H3;           // 24832 .. 29056
-constexpr int O_H5 = 0;                          // 2176
-constexpr int O_LAT = 32 * S_H5;                 // 2176 .. 3328
-constexpr int O_HB = 0;                          // 24704
-constexpr int O_HA = 32 * S_HB;                  // 24704 .. 37120
-constexpr int O_HC = O_HA;
-constexpr int O_HD = 0;
-constexpr int LDS_FLOATS = O_XS + 2 * 32 * S_XS;  // 37248 floats = 148992 B
-static_assert(O_HA + 32 * S_HA <= LDS_FLOATS, "LDS map");
-static_assert(O_H4 + 32 * S_H4 <= LDS_FLOATS, "LDS map");
+constexpr int O_H1H = 0;                          // 64*516 = 33024; pass A, then pass B in place
+constexpr int O_XS = 64 * S_H1H;                  // 2 slabs x 64*36 = 4608  -> ends 37632
+constexpr int O_H2 = 0;                           // written after E1's last K loop (barrier)
+constexpr int O_H3 = 0;                           // written after E2's K loop (barrier): 64*260 = 16640
+constexpr int O_H4 = O_H3 + 64 * S_H3;            // 16640 .. 25088
+constexpr int O_H5 = O_H4 + 64 * S_H4;            // 25088 .. 29440
+constexpr int O_LAT = 38656;                      // 64*36 = 2304 -> ends 40960; survives both head passes
+constexpr int O_HA = 0;                           // 32*388 = 12416
+constexpr int O_HB = O_HA + 32 * S_HA;            // 12416 .. 37120
+constexpr int O_HC = 0;
+constexpr int O_HD = O_HB;
+constexpr int LDS_FLOATS = 40960;                 // 160 KiB
+static_assert(O_XS + 2 * 64 * S_XS <= O_LAT, "LDS map");
+static_assert(O_H5 + 64 * S_H5 <= O_LAT, "LDS map");
+static_assert(O_HB + 32 * S_HB <= O_LAT, "LDS map");
+static_assert(O_LAT + 64 * S_LAT <= LDS_FLOATS, "LDS map");
 
 }  // namespace nlml

@@ -68,7 +68,7 @@ def encoder_heads_fwd(x: torch.Tensor, blob: torch.Tensor, F: int, return_latent
 
 
 def encoder_heads_fwd_debug(x: torch.Tensor, blob: torch.Tensor, F: int, want_stamps: bool = False):
-    """Diagnostic build: (out [B,3], latent [B,9], pre_tanh [B,64][, stamps i64[tiles,4,16]]); include/nlml_hpe.h."""
+    """Diagnostic build: (out [B,3], latent [B,9], pre_tanh [B,64][, stamps i64[ceil(B/64),4,16]]); include/nlml_hpe.h."""
     _need_cuda(x, "x", torch.float32)
     _need_cuda(blob, "blob", torch.uint8)
     if x.dim() != 2 or x.shape[1] != F:
@@ -78,7 +78,7 @@ def encoder_heads_fwd_debug(x: torch.Tensor, blob: torch.Tensor, F: int, want_st
     out = torch.empty((B, 3), dtype=torch.float32, device=x.device)
     latent = torch.empty((B, LATENT), dtype=torch.float32, device=x.device)
     pre = torch.empty((B, 64), dtype=torch.float32, device=x.device)
-    stamps = torch.zeros(((B + 31) // 32, 4, 16), dtype=torch.int64, device=x.device) if want_stamps else None
+    stamps = torch.zeros(((B + 63) // 64, 4, 16), dtype=torch.int64, device=x.device) if want_stamps else None
     _lib.check(_lib.lib().nlml_encoder_heads_fwd_debug(x.data_ptr(), F, B, F, blob.data_ptr(), blob.numel(),
                                                        out.data_ptr(), latent.data_ptr(), pre.data_ptr(),
                                                        stamps.data_ptr() if want_stamps else None, _stream_ptr()),

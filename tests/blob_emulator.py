@@ -9,13 +9,13 @@ kernel implements this walk.
 import numpy as np
 
 # (nb, jobs, k8) per stage; E0's k8 comes from the header
-STAGES = [(8, 4, None), (4, 4, 128), (2, 4, 64), (1, 4, 32), (1, 2, 16), (1, 1, 8),
+STAGES = [(4, 8, None), (4, 4, 128), (2, 4, 64), (1, 4, 32), (1, 2, 16), (1, 1, 8),
           (1, 12, 1), (2, 12, 16), (1, 12, 32), (1, 6, 16), (1, 3, 8)]
 
 
 def _header(blob):
     u = blob[:256].view(np.uint32)
-    assert u[0] == 0x4E4C4D4C and u[1] == 1
+    assert u[0] == 0x4E4C4D4C and u[1] == 2
     return {"F": int(u[2]), "mode": int(u[3]), "k8_e0": int(u[4]), "total16": int(u[5]),
             "w_off": u[6:17].astype(np.int64), "b_off": u[17:28].astype(np.int64), "job_w16": u[28:39].astype(np.int64)}
 
@@ -50,8 +50,8 @@ def forward(blob: np.ndarray, x: np.ndarray) -> tuple:
     xin[:, :F] = x
     relu = lambda v: np.maximum(v, 0)
     h1 = np.zeros((32, 1024))
-    for wv in range(4):
-        h1[:, 256 * wv:256 * wv + 256] = relu(_job(bf, hdr, 0, wv, xin, k8, 8)).T
+    for job in range(8):                    # jobs 0-3: pass A (neurons 0..511), 4-7: pass B; job = 4*pass + wave
+        h1[:, 128 * job:128 * job + 128] = relu(_job(bf, hdr, 0, job, xin, k8, 4)).T
     h2 = np.zeros((32, 512))
     for wv in range(4):
         h2[:, 128 * wv:128 * wv + 128] = relu(_job(bf, hdr, 1, wv, h1, 128, 4)).T

@@ -13,14 +13,17 @@ for _ in range(2):
     out, lat, pre, st = ops.encoder_heads_fwd_debug(x, blob, F, want_stamps=True)
 torch.cuda.synchronize()
 st = st.cpu().numpy().astype(np.int64)            # [tiles, 4 waves, 16]
-names = ["E0 kloop", "E0 store+bar", "E1 kloop", "E1 bar+store+bar", "E2", "E3", "E4", "E5(+latent)", "H0", "H1", "H2", "H3", "H4"]
+names = ["E0a kloop", "E0a store+bar", "E1a kloop", "E1a bar", "E0b kloop", "E0b store+bar", "E1b kloop", "E1b bar",
+         "valid+h2 store+bar", "E2", "E3", "E4+E5", "heads (2 x 32 faces)"]
 d = np.diff(st[:, :, :14], axis=2).astype(np.float64)   # [tiles,4,13]
 tot = (st[:, :, 13] - st[:, :, 0]).astype(np.float64)
-print(f"tiles {st.shape[0]}  mean cycles/tile (wave avg) {tot.mean():,.0f}  min {tot.min():,.0f} max {tot.max():,.0f}")
-ideal = {"E0 kloop": 176*32*64, "E1 kloop": 128*16*64, "E2": 64*8*64, "E3": 32*4*64, "E4": 16*4*64, "E5(+latent)": 8*4*64,
-         "H0": 3*4*64, "H1": 3*16*8*64, "H2": 3*32*4*64, "H3": 2*16*4*64, "H4": 8*4*64}
+print(f"tiles {st.shape[0]} (64 faces)  mean cycles/tile (wave avg) {tot.mean():,.0f}  min {tot.min():,.0f} max {tot.max():,.0f}")
+M = 64  # cycles per MFMA
+ideal = {"E0a kloop": 176*32*M, "E0b kloop": 176*32*M, "E1a kloop": 64*32*M, "E1b kloop": 64*32*M, "E2": 64*16*M, "E3": 32*8*M,
+         "E4+E5": (16*4 + 8*4)*M, "heads (2 x 32 faces)": 2*(3*4 + 3*16*8 + 3*32*4 + 2*16*4 + 8*4)*M}
 for i, n in enumerate(names):
     m = d[:, :, i].mean()
     extra = f"  ideal MFMA {ideal[n]:,}  ({ideal[n]/m*100:.0f}% busy)" if n in ideal else ""
-    print(f"{n:18s} {m:10,.0f} cyc  {m/tot.mean()*100:5.1f}%{extra}")
+    print(f"{n:22s} {m:10,.0f} cyc  {m/tot.mean()*100:5.1f}%{extra}")
 print("per-wave totals:", [f"{tot[:, w].mean():,.0f}" for w in range(4)])
+print(f"sum of ideal MFMA cycles {sum(ideal.values()):,} = {sum(ideal.values())/tot.mean()*100:.1f}% of the tile")
