@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnlml_hpe_hip.so")
+# NLML_HPE_LIB overrides the path (A/B experiments with alternative builds); default: the in-tree build
+LIB_PATH = os.environ.get("NLML_HPE_LIB") or os.path.join(_HERE, "libnlml_hpe_hip.so")
 
 # Every symbol include/nlml_hpe.h declares: (restype, argtypes)
 _c_f32p = C.c_void_p

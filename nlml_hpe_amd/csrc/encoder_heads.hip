@@ -93,6 +93,32 @@ __device__ __forceinline__ void mfma_step(f32x16 (&acc)[NB][NFB], const f32x4 (&
         acc[nb][fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[nb][j], x[fb][j], acc[nb][fb], 0, 0, 0);
 }
 
+// One K step with its prefetch folded in: the NB weight loads of a later step (into ring slot `wnext`) and
+// the x fragment reads are issued one at a time in the gaps BETWEEN the four sub-steps' MFMA groups, each
+// gap pinned by sched_barrier.  Issued as a block ahead of the 32 MFMAs they cost ~100 cycles of idle
+// matrix pipe per step; one load per gap hides under the 64 cycles the previous MFMA is still executing.
+// `between(j)` lets the caller drop extra work (layer 0's x staging) into gap j.
+template <int NB, int NFB, typename XLoad, typename Between>
+__device__ __forceinline__ void step_interleaved(f32x16 (&acc)[NB][NFB], const f32x4 (&wcur)[NB],
+                                                 const f32x4 (&xcur)[NFB], f32x4 (&wnext)[NB],
+                                                 const f32x4* __restrict__ wp, XLoad xload, Between between) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      if ((nb * 4) / NB == j) wnext[nb] = wp[nb * 64];   // static: NB 4 -> one load per gap
+    if (j == 0) xload();
+    between(j);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb)
+        acc[nb][fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[nb][j], xcur[fb][j], acc[nb][fb], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Prefetch ring.  The compiler, left alone, sinks the weight loads of step s+1 below the MFMAs of
 // step s and then waits for them at once (34 % of wave cycles parked in s_waitcnt, profiles/r01):
 // so the K loops are unrolled over a ring of R register buffers with the loads of step s+D
@@ -100,41 +126,49 @@ __device__ __forceinline__ void mfma_step(f32x16 (&acc)[NB][NFB], const f32x4 (&
 // MFMA; D steps must cover an L2 miss (Infinity-Cache round trip, ~2 us under load).
 template <int NB, int NFB> struct Ring { static constexpr int R = (NB * NFB >= 8) ? 4 : 8; };
 
-// K loop with the input image resident in LDS.  `w` points at this lane's first fragment of the
-// job's FIRST K step to run, `in` at this lane's (face row of block 0, k-half) of the input image
-// at that step; face block fb is fb_stride floats further.  Weight loads run up to D steps past
-// the last step (next job / tail pad of the blob: harmless); LDS reads are clamped.
-template <int NB, int NFB>
+// K loop with the input image resident in LDS; K8 (steps of 8) is static, so the loop has NO runtime
+// branch: a conditional inside the unrolled body makes the compiler lose the exact load count at the
+// join and fall back to s_waitcnt vmcnt(0), which drains the whole ring every step.
+// `w` points at this lane's first fragment of the FIRST K step to run, `in` at this lane's (face row of
+// block 0, k-half) of the input image at that step; face block fb is fb_stride floats further.
+// Weight loads run up to D steps past the last step (next job / tail pad of the blob: harmless).
+template <int NB, int NFB, int K8>
 __device__ __forceinline__ void kloop_lds(f32x16 (&acc)[NB][NFB], const f32x4* __restrict__ w,
-                                          const float* in, int fb_stride, int k8) {
+                                          const float* in, int fb_stride) {
   constexpr int R = Ring<NB, NFB>::R, D = R - 1;
   f32x4 wr[R][NB];
   f32x4 xr[R][NFB];
 #pragma unroll
   for (int d = 0; d < D; ++d) {
+    if (d < K8) {  // static
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) wr[d][nb] = w[(d * NB + nb) * 64];
+      for (int nb = 0; nb < NB; ++nb) wr[d][nb] = w[(d * NB + nb) * 64];
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb)
-      xr[d][fb] = *reinterpret_cast<const f32x4*>(in + fb * fb_stride + 8 * (d < k8 ? d : k8 - 1));
+      for (int fb = 0; fb < NFB; ++fb) xr[d][fb] = *reinterpret_cast<const f32x4*>(in + fb * fb_stride + 8 * d);
+    }
   }
-  for (int s0 = 0; s0 < k8; s0 += R) {
+  constexpr int GROUPS = K8 / R, TAIL = K8 % R;
+  for (int g = 0; g < GROUPS; ++g) {
+    const int s0 = g * R;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int s = s0 + r;
-      if (s < k8) {
-        const int sp = s + D;
-        const f32x4* wp = w + (size_t)sp * (NB * 64);
+      const int sp = s0 + r + D;
+      const int spx = sp < K8 ? sp : K8 - 1;   // the LDS read stays inside the image
+      step_interleaved<NB, NFB>(
+          acc, wr[r], xr[r], wr[(r + D) % R], w + (size_t)sp * (NB * 64),
+          [&]() {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) wr[(r + D) % R][nb] = wp[nb * 64];
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb)
-          xr[(r + D) % R][fb] = *reinterpret_cast<const f32x4*>(in + fb * fb_stride + 8 * (sp < k8 ? sp : k8 - 1));
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step<NB, NFB>(acc, wr[r], xr[r]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+            for (int fb = 0; fb < NFB; ++fb)
+              xr[(r + D) % R][fb] = *reinterpret_cast<const f32x4*>(in + fb * fb_stride + 8 * spx);
+          },
+          [](int) {});
     }
+  }
+#pragma unroll
+  for (int r = 0; r < TAIL; ++r) {  // static tail (only jobs shorter than the ring: H0)
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step<NB, NFB>(acc, wr[r], xr[r]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -157,6 +191,64 @@ __device__ __forceinline__ void store_lds(const f32x16 (&acc)[NB][NFB], float* o
       }
 }
 
+// Grouped K loop for the heads: NJ independent jobs of NB neuron blocks each (one 32-face block), every
+// job with ITS OWN input slice (a different head, or a different column range), walked in lock step
+// through one weight ring.  The three jobs a wave owns in a head stage used to run one after the
+// other, each paying its own ring fill (an exposed L2 round trip) for 16-32 short steps; together they
+// pay it once and put NJ*NB*4 MFMAs behind every step.  Jobs j of a wave are adjacent in the blob:
+// job j's fragments start job_stride (in float4) after job j-1's.
+template <int NJ, int NB, int K8>
+__device__ __forceinline__ void kloop_grouped(f32x16 (&acc)[NJ][NB][1], const f32x4* __restrict__ w0,
+                                              size_t job_stride, const float* const (&in)[NJ]) {
+  constexpr int NT = NJ * NB;
+  constexpr int R = (NT >= 6) ? 4 : 8, D = R - 1;
+  f32x4 wr[R][NJ][NB];
+  f32x4 xr[R][NJ];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    if (d < K8) {  // static
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) wr[d][j][nb] = w0[j * job_stride + (d * NB + nb) * 64];
+        xr[d][j] = *reinterpret_cast<const f32x4*>(in[j] + 8 * d);
+      }
+    }
+  }
+  auto step = [&](int r, int sp, bool prefetch) {
+    const int spx = sp < K8 ? sp : K8 - 1;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      if (prefetch) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            if (((j * NB + nb) * 4) / NT == jj)   // static: spread the NT loads over the four gaps
+              wr[(r + D) % R][j][nb] = w0[j * job_stride + ((size_t)sp * NB + nb) * 64];
+        if (jj == 0) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) xr[(r + D) % R][j] = *reinterpret_cast<const f32x4*>(in[j] + 8 * spx);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[j][nb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[r][j][nb][jj], xr[r][j][jj], acc[j][nb][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  constexpr int GROUPS = K8 / R, TAIL = K8 % R;
+  for (int g = 0; g < GROUPS; ++g) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) step(r, g * R + r + D, true);
+  }
+#pragma unroll
+  for (int r = 0; r < TAIL; ++r) step(r, 0, false);   // static tail (H0: a single step)
+}
+
 struct Ctx {
   const f32x4* blob4;
   const Header* hdr;
@@ -165,12 +257,13 @@ struct Ctx {
 };
 
 // Bias init + K loop of one job over an LDS image.  face0: first face row (0 or 32) of the job.
-template <int NB, int NFB>
-__device__ __forceinline__ void job_compute(const Ctx& c, int stage, int job, f32x16 (&acc)[NB][NFB],
-                                            const float* in_img, int in_stride, int in_col, int face0, int k8) {
-  load_bias<NB, NFB>(acc, c.blob4 + c.hdr->b_off[stage] + job * (NB * 8), c.h);
-  const f32x4* w = c.blob4 + c.hdr->w_off[stage] + (size_t)job * c.hdr->job_w16[stage] + c.lane;
-  kloop_lds<NB, NFB>(acc, w, in_img + (face0 + c.f) * in_stride + in_col + 4 * c.h, 32 * in_stride, k8);
+template <int NB, int NFB, int STAGE>
+__device__ __forceinline__ void job_compute(const Ctx& c, int job, f32x16 (&acc)[NB][NFB],
+                                            const float* in_img, int in_stride, int in_col, int face0) {
+  static_assert(kStages[STAGE].nb == NB, "job shape");
+  load_bias<NB, NFB>(acc, c.blob4 + c.hdr->b_off[STAGE] + job * (NB * 8), c.h);
+  const f32x4* w = c.blob4 + c.hdr->w_off[STAGE] + (size_t)job * c.hdr->job_w16[STAGE] + c.lane;
+  kloop_lds<NB, NFB, kStages[STAGE].k8>(acc, w, in_img + (face0 + c.f) * in_stride + in_col + 4 * c.h, 32 * in_stride);
 }
 
 template <int NB, int NFB, int ACT>
@@ -186,7 +279,8 @@ struct E0Stager {
   const float *p0, *p1;       // this thread's two rows (srow, srow + 32)
   double ref0[3], ref1[3], ipd0, ipd1;
   int srow, scol;
-  bool live0, live1, nz0, nz1;
+  bool live0, live1;
+  unsigned nzbits0, nzbits1;   // OR of the magnitude bits of every staged value of the row
 };
 
 template <bool NORM>
@@ -200,7 +294,7 @@ __device__ __forceinline__ void e0_stager_init(E0Stager& g, const EncArgs& a, in
   r1 = g.live1 ? r1 : a.B - 1;
   g.p0 = a.x + r0 * a.ldx;
   g.p1 = a.x + r1 * a.ldx;
-  g.nz0 = g.nz1 = false;
+  g.nzbits0 = g.nzbits1 = 0u;
   g.ipd0 = g.ipd1 = 1.0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) g.ref0[k] = g.ref1[k] = 0.0;
@@ -226,53 +320,69 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
   constexpr int NB = 4, NFB = 2;
   float* xs = c.lds + O_XS;
   const int F = a.F;
-  const int k8_total = (int)c.hdr->k8_e0;
-  const int nslab = (F + XS_COLS - 1) / XS_COLS;
+  const int nslab = (int)c.hdr->k8_e0 / XS_STEPS;   // even: k8_e0 is a multiple of 2*XS_STEPS (pack.cpp)
 
-  f32x4 s0, s1;
-  auto gload = [&](int s) {
+  // x staging, software-pipelined over THREE LDS slab buffers (slab j lives in buffer j % 3):
+  //   top of slab s     issue the global loads of slab s+3 into one of two register sets;
+  //   middle of slab s  write slab s+2 (loaded during slab s-1) to LDS, under the MFMAs of steps 2,3;
+  //   end of slab s     read the first x fragments of slab s+1 (written during slab s-1, published by
+  //                     the barrier that ended slab s-1), then the barrier.
+  // So a load has ~1.5 slabs (12k cycles) to arrive, nothing that depends on it sits before MFMAs,
+  // and after the barrier the next slab's operands are already in registers.
+  // Loads are UNCONDITIONAL (clamped address; the zero padding is a select at write time): an
+  // exec-masked load makes the compiler wait vmcnt(0) around it and drain the weight ring.
+  auto gload = [&](int s, f32x4 (&st)[2]) {
+    s = s < nslab ? s : nslab - 1;
     const int k = s * XS_COLS + g.scol;
     if (VEC4) {
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      s0 = (k < F) ? *reinterpret_cast<const f32x4*>(g.p0 + k) : z;
-      s1 = (k < F) ? *reinterpret_cast<const f32x4*>(g.p1 + k) : z;
+      const int kc = k < F ? k : F - 4;
+      st[0] = *reinterpret_cast<const f32x4*>(g.p0 + kc);
+      st[1] = *reinterpret_cast<const f32x4*>(g.p1 + kc);
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        s0[e] = (k + e < F) ? g.p0[k + e] : 0.f;
-        s1[e] = (k + e < F) ? g.p1[k + e] : 0.f;
+        const int kc = k + e < F ? k + e : F - 1;
+        st[0][e] = g.p0[kc];
+        st[1][e] = g.p1[kc];
       }
     }
   };
-  auto lwrite = [&](int s, int buf) {
+  // Columns >= F need no zeroing: their weights are zero in the blob (pack.cpp pads K), the clamped loads
+  // return finite values of the same row, and 0 * finite contributes exactly 0.  The "row is all zero"
+  // test is an OR of the magnitude bits (one v_and_or per value, no compare chains); clamped duplicates
+  // repeat real columns, and the OR is idempotent.
+  auto lwrite = [&](int s, int buf_off, f32x4 (&st)[2]) {
+    asm volatile("" : "+v"(st[0]), "+v"(st[1]));   // consumers of the loaded values stay where written
     if (NORM) {
-      const int k = s * XS_COLS + g.scol;
-      int cidx = k % 3;
+      const int k = (s < nslab ? s : nslab - 1) * XS_COLS + g.scol;
+      int cidx = (k < F ? k : F - 4) % 3;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (k + e < F) {  // explicit selects: a runtime-indexed array would live in scratch
-          const double r0 = cidx == 0 ? g.ref0[0] : (cidx == 1 ? g.ref0[1] : g.ref0[2]);
-          const double r1 = cidx == 0 ? g.ref1[0] : (cidx == 1 ? g.ref1[1] : g.ref1[2]);
-          s0[e] = (float)(((double)s0[e] - r0) / g.ipd0);
-          s1[e] = (float)(((double)s1[e] - r1) / g.ipd1);
-        }
+      for (int e = 0; e < 4; ++e) {  // explicit selects: a runtime-indexed array would live in scratch
+        const double r0 = cidx == 0 ? g.ref0[0] : (cidx == 1 ? g.ref0[1] : g.ref0[2]);
+        const double r1 = cidx == 0 ? g.ref1[0] : (cidx == 1 ? g.ref1[1] : g.ref1[2]);
+        st[0][e] = (float)(((double)st[0][e] - r0) / g.ipd0);
+        st[1][e] = (float)(((double)st[1][e] - r1) / g.ipd1);
         cidx = (cidx == 2) ? 0 : cidx + 1;
       }
     }
-    g.nz0 |= (s0[0] != 0.f) | (s0[1] != 0.f) | (s0[2] != 0.f) | (s0[3] != 0.f);
-    g.nz1 |= (s1[0] != 0.f) | (s1[1] != 0.f) | (s1[2] != 0.f) | (s1[3] != 0.f);
-    float* d = xs + buf * (64 * S_XS);
-    *reinterpret_cast<f32x4*>(d + g.srow * S_XS + g.scol) = s0;
-    *reinterpret_cast<f32x4*>(d + (g.srow + 32) * S_XS + g.scol) = s1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      g.nzbits0 |= __float_as_uint(st[0][e]) & 0x7fffffffu;
+      g.nzbits1 |= __float_as_uint(st[1][e]) & 0x7fffffffu;
+    }
+    float* d = xs + buf_off;
+    *reinterpret_cast<f32x4*>(d + g.srow * S_XS + g.scol) = st[0];
+    *reinterpret_cast<f32x4*>(d + (g.srow + 32) * S_XS + g.scol) = st[1];
   };
 
   load_bias<NB, NFB>(acc, c.blob4 + c.hdr->b_off[ST_E0] + job * (NB * 8), c.h);
   const f32x4* w = c.blob4 + c.hdr->w_off[ST_E0] + (size_t)job * c.hdr->job_w16[ST_E0] + c.lane;
 
-  gload(0);
-  lwrite(0, 0);
-  // weight ring of R0 = 4 slots: K step ks lives in slot ks % 4; a full slab holds 4 steps, so the slot
-  // of every step is static inside the unrolled slab body.  x ring of 2 inside the slab.
+  f32x4 setA[2], setB[2];
+  gload(0, setA);
+  gload(1, setB);
+  // weight ring of R0 = 4 slots: K step ks lives in slot ks % 4 and every slab holds exactly 4 steps
+  // (the packer pads layer 0's K with zero weights), so the slot of every step is static.
   constexpr int R0 = 4, D0 = R0 - 1;
   static_assert(XS_STEPS == R0, "slab steps == ring slots keeps the slot index static");
   f32x4 wr[R0][NB];
@@ -280,36 +390,48 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
   for (int d = 0; d < D0; ++d)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) wr[d][nb] = w[(d * NB + nb) * 64];
+  constexpr int SLAB = 64 * S_XS;
+  lwrite(0, 0, setA);
+  lwrite(1, SLAB, setB);
+  gload(2, setA);
   __syncthreads();
 
-  int ks = 0;
-  for (int s = 0; s < nslab; ++s) {
-    const bool more = s + 1 < nslab;
-    if (more) gload(s + 1);
-    const float* xrow = xs + (s & 1) * (64 * S_XS) + c.f * S_XS + 4 * c.h;
-    int nk = k8_total - ks;
-    nk = nk > XS_STEPS ? XS_STEPS : nk;
-    f32x4 xr[2][NFB];
+  const int lane_off = c.f * S_XS + 4 * c.h;
+  f32x4 xr[2][NFB];
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) xr[0][fb] = *reinterpret_cast<const f32x4*>(xrow + fb * (32 * S_XS));
+  for (int fb = 0; fb < NFB; ++fb) xr[0][fb] = *reinterpret_cast<const f32x4*>(xs + lane_off + fb * (32 * S_XS));
+
+  // one slab: `ld` receives the global loads of slab s+3, `wrset` (loaded one slab earlier) is written as
+  // slab s+2.  o_cur / o_next / o_wr: LDS offsets of the buffers of slabs s, s+1, s+2 (rotated by the caller,
+  // so no modulo-3 arithmetic sits between the MFMAs).
+  auto slab = [&](int s, int o_cur, int o_next, int o_wr, f32x4 (&ld)[2], f32x4 (&wrset)[2]) {
+    gload(s + 3, ld);
+    const float* xrow = xs + o_cur + lane_off;
+    const float* xnext = xs + o_next + lane_off;
 #pragma unroll
     for (int kk = 0; kk < XS_STEPS; ++kk) {
-      if (kk < nk) {
-        const f32x4* wp = w + (size_t)(ks + kk + D0) * (NB * 64);
+      step_interleaved<NB, NFB>(
+          acc, wr[kk % R0], xr[kk & 1], wr[(kk + D0) % R0], w + (size_t)(s * XS_STEPS + kk + D0) * (NB * 64),
+          [&]() {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) wr[(kk + D0) % R0][nb] = wp[nb * 64];
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb)
-          xr[(kk + 1) & 1][fb] =
-              *reinterpret_cast<const f32x4*>(xrow + fb * (32 * S_XS) + 8 * (kk + 1 < nk ? kk + 1 : kk));
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step<NB, NFB>(acc, wr[kk % R0], xr[kk & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+            for (int fb = 0; fb < NFB; ++fb)
+              xr[(kk + 1) & 1][fb] = (kk + 1 < XS_STEPS)
+                                         ? *reinterpret_cast<const f32x4*>(xrow + fb * (32 * S_XS) + 8 * (kk + 1))
+                                         : *reinterpret_cast<const f32x4*>(xnext + fb * (32 * S_XS));
+          },
+          [&](int j) {
+            if (kk == 2 && j == 1) lwrite(s + 2, o_wr, wrset);   // static condition
+          });
     }
-    ks += nk;
-    if (more) lwrite(s + 1, (s + 1) & 1);
     __syncthreads();
+  };
+  // nslab is even (pack.cpp pads K to whole PAIRS of slabs): the two register sets alternate statically
+  int o0 = 0, o1 = SLAB, o2 = 2 * SLAB;   // buffers of slabs s, s+1, s+2
+  for (int s = 0; s < nslab; s += 2) {
+    slab(s, o0, o1, o2, setB, setA);
+    slab(s + 1, o1, o2, o0, setA, setB);
+    const int t0 = o0, t1 = o1;          // advance by two slabs: (o0,o1,o2) <- (o2,o0,o1)
+    o0 = o2; o1 = t0; o2 = t1;
   }
 }
 
@@ -358,13 +480,13 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
       __syncthreads();
       NLML_STAMP(2 + 4 * pass);
       // E1 over this K half: k = 512*pass .. +511  (64 steps of 8)
-      kloop_lds<4, 2>(acc1, w1 + (size_t)pass * 64 * (4 * 64), lds + O_H1H + c.f * S_H1H + 4 * c.h, 32 * S_H1H, 64);
+      kloop_lds<4, 2, 64>(acc1, w1 + (size_t)pass * 64 * (4 * 64), lds + O_H1H + c.f * S_H1H + 4 * c.h, 32 * S_H1H);
       NLML_STAMP(3 + 4 * pass);
       __syncthreads();  // all waves done reading this h1 half before it is overwritten
       NLML_STAMP(4 + 4 * pass);
     }
     if (a.valid) {  // all-zero feature row == "no face" (FeatureExtractor.py:105-106)
-      const unsigned long long m0 = __ballot(g.nz0), m1 = __ballot(g.nz1);
+      const unsigned long long m0 = __ballot(g.nzbits0 != 0u), m1 = __ballot(g.nzbits1 != 0u);
       if ((tid & 7) == 0) {
         const int sh = c.lane & 56;
         if (g.live0) a.valid[row0 + g.srow] = ((m0 >> sh) & 0xFFull) ? 1 : 0;
@@ -377,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
   NLML_STAMP(9);
   {  // E2: 512 -> 256, ReLU.  h3 overwrites h2 => barrier between the K loop and the store
     f32x16 acc[2][2];
-    job_compute<2, 2>(c, ST_E2, wv, acc, lds + O_H2, S_H2, 0, 0, kStages[ST_E2].k8);
+    job_compute<2, 2, ST_E2>(c, wv, acc, lds + O_H2, S_H2, 0, 0);
     __syncthreads();
     job_store<2, 2, ACT_RELU>(c, acc, lds + O_H3, S_H3, 64 * wv, 0);
   }
@@ -385,7 +507,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
   NLML_STAMP(10);
   {  // E3: 256 -> 128, ReLU
     f32x16 acc[1][2];
-    job_compute<1, 2>(c, ST_E3, wv, acc, lds + O_H3, S_H3, 0, 0, kStages[ST_E3].k8);
+    job_compute<1, 2, ST_E3>(c, wv, acc, lds + O_H3, S_H3, 0, 0);
     job_store<1, 2, ACT_RELU>(c, acc, lds + O_H4, S_H4, 32 * wv, 0);
   }
   __syncthreads();
@@ -393,7 +515,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
   {  // E4: 128 -> 64, Tanh.  4 single-face-block jobs: neuron block wv&1, face block wv>>1
     const int nb = wv & 1, face0 = 32 * (wv >> 1);
     f32x16 acc[1][1];
-    job_compute<1, 1>(c, ST_E4, nb, acc, lds + O_H4, S_H4, 0, face0, kStages[ST_E4].k8);
+    job_compute<1, 1, ST_E4>(c, nb, acc, lds + O_H4, S_H4, 0, face0);
     if (DBG && a.pre_tanh && row0 + face0 + c.f < a.B) {
 #pragma unroll
       for (int q = 0; q < 16; ++q)
@@ -404,7 +526,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
   __syncthreads();
   if (wv < 2) {  // E5: 64 -> 9 (latent n = 3g+c on row 8g+c, other rows exact zeros); face block wv
     f32x16 acc[1][1];
-    job_compute<1, 1>(c, ST_E5, 0, acc, lds + O_H5, S_H5, 0, 32 * wv, kStages[ST_E5].k8);
+    job_compute<1, 1, ST_E5>(c, 0, acc, lds + O_H5, S_H5, 0, 32 * wv);
     job_store<1, 1, ACT_NONE>(c, acc, lds + O_LAT, S_LAT, 0, 32 * wv);
   }
   __syncthreads();
@@ -415,45 +537,89 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
       if (row0 + ff < a.B) a.latent[(row0 + ff) * NLML_LATENT + n] = lds[O_LAT + ff * S_LAT + 8 * (n / 3) + (n % 3)];
     }
   }
-  // ---- heads (yaw, pitch, roll = g 0,1,2), one 32-face block at a time; jobs are (head, neuron block)
+  // ---- heads (yaw, pitch, roll = g 0,1,2), one 32-face block at a time.  A stage's jobs are (head,
+  // neuron block) pairs; the jobs a wave owns run together through kloop_grouped.
 #pragma unroll 1
   for (int fb = 0; fb < 2; ++fb) {
     const int face0 = 32 * fb;
-#pragma unroll 1
-    for (int i = 0; i < 3; ++i) {  // H0: 3 -> 128 (K padded to 8 with zeros), ReLU
-      const int job = wv * 3 + i, g = job >> 2, nb = job & 3;
-      f32x16 acc[1][1];
-      job_compute<1, 1>(c, ST_H0, job, acc, lds + O_LAT, S_LAT, 8 * g, face0, 1);
-      job_store<1, 1, ACT_RELU>(c, acc, lds + O_HA, S_HA, 128 * g + 32 * nb, 0);
+    const int lrow = c.f;   // row of the 32-face head images
+    {  // H0: 3 -> 128 (K padded to 8 with zeros), ReLU.  12 jobs (g, nb), 3 per wave
+      constexpr int ST = ST_H0;
+      f32x16 acc[3][1][1];
+      const float* in[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int job = wv * 3 + j;
+        load_bias<1, 1>(acc[j], c.blob4 + c.hdr->b_off[ST] + job * 8, c.h);
+        in[j] = lds + O_LAT + (face0 + c.f) * S_LAT + 8 * (job >> 2) + 4 * c.h;
+      }
+      kloop_grouped<3, 1, kStages[ST].k8>(acc, c.blob4 + c.hdr->w_off[ST] + (size_t)(wv * 3) * c.hdr->job_w16[ST] + c.lane,
+                                          c.hdr->job_w16[ST], in);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int job = wv * 3 + j;
+        store_lds<1, 1, ACT_RELU>(acc[j], lds + O_HA + lrow * S_HA + 128 * (job >> 2) + 32 * (job & 3) + 4 * c.h, 0);
+      }
     }
     __syncthreads();
-#pragma unroll 1
-    for (int i = 0; i < 3; ++i) {  // H1: 128 -> 256, ReLU
-      const int job = wv * 3 + i, g = job >> 2, p = job & 3;
-      f32x16 acc[2][1];
-      job_compute<2, 1>(c, ST_H1, job, acc, lds + O_HA, S_HA, 128 * g, 0, kStages[ST_H1].k8);
-      job_store<2, 1, ACT_RELU>(c, acc, lds + O_HB, S_HB, 256 * g + 64 * p, 0);
+    {  // H1: 128 -> 256, ReLU.  12 jobs (g, pair of blocks), 3 per wave
+      constexpr int ST = ST_H1;
+      f32x16 acc[3][2][1];
+      const float* in[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int job = wv * 3 + j;
+        load_bias<2, 1>(acc[j], c.blob4 + c.hdr->b_off[ST] + job * 16, c.h);
+        in[j] = lds + O_HA + lrow * S_HA + 128 * (job >> 2) + 4 * c.h;
+      }
+      kloop_grouped<3, 2, kStages[ST].k8>(acc, c.blob4 + c.hdr->w_off[ST] + (size_t)(wv * 3) * c.hdr->job_w16[ST] + c.lane,
+                                          c.hdr->job_w16[ST], in);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int job = wv * 3 + j;
+        store_lds<2, 1, ACT_RELU>(acc[j], lds + O_HB + lrow * S_HB + 256 * (job >> 2) + 64 * (job & 3) + 4 * c.h, 0);
+      }
     }
     __syncthreads();
-#pragma unroll 1
-    for (int i = 0; i < 3; ++i) {  // H2: 256 -> 128, ReLU
-      const int job = wv * 3 + i, g = job >> 2, nb = job & 3;
-      f32x16 acc[1][1];
-      job_compute<1, 1>(c, ST_H2, job, acc, lds + O_HB, S_HB, 256 * g, 0, kStages[ST_H2].k8);
-      job_store<1, 1, ACT_RELU>(c, acc, lds + O_HC, S_HC, 128 * g + 32 * nb, 0);
+    {  // H2: 256 -> 128, ReLU.  12 jobs (g, nb), 3 per wave
+      constexpr int ST = ST_H2;
+      f32x16 acc[3][1][1];
+      const float* in[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int job = wv * 3 + j;
+        load_bias<1, 1>(acc[j], c.blob4 + c.hdr->b_off[ST] + job * 8, c.h);
+        in[j] = lds + O_HB + lrow * S_HB + 256 * (job >> 2) + 4 * c.h;
+      }
+      kloop_grouped<3, 1, kStages[ST].k8>(acc, c.blob4 + c.hdr->w_off[ST] + (size_t)(wv * 3) * c.hdr->job_w16[ST] + c.lane,
+                                          c.hdr->job_w16[ST], in);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int job = wv * 3 + j;
+        store_lds<1, 1, ACT_RELU>(acc[j], lds + O_HC + lrow * S_HC + 128 * (job >> 2) + 32 * (job & 3) + 4 * c.h, 0);
+      }
     }
     __syncthreads();
-#pragma unroll 1
-    for (int job = wv; job < 6; job += 4) {  // H3: 128 -> 64, ReLU
-      const int g = job >> 1, nb = job & 1;
-      f32x16 acc[1][1];
-      job_compute<1, 1>(c, ST_H3, job, acc, lds + O_HC, S_HC, 128 * g, 0, kStages[ST_H3].k8);
-      job_store<1, 1, ACT_RELU>(c, acc, lds + O_HD, S_HD, 64 * g + 32 * nb, 0);
+    if (wv < 3) {  // H3: 128 -> 64, ReLU.  6 jobs (g, nb): waves 0..2 take the two blocks of head wv
+      constexpr int ST = ST_H3;
+      f32x16 acc[2][1][1];
+      const float* in[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int job = wv * 2 + j;
+        load_bias<1, 1>(acc[j], c.blob4 + c.hdr->b_off[ST] + job * 8, c.h);
+        in[j] = lds + O_HC + lrow * S_HC + 128 * wv + 4 * c.h;
+      }
+      kloop_grouped<2, 1, kStages[ST].k8>(acc, c.blob4 + c.hdr->w_off[ST] + (size_t)(wv * 2) * c.hdr->job_w16[ST] + c.lane,
+                                          c.hdr->job_w16[ST], in);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        store_lds<1, 1, ACT_RELU>(acc[j], lds + O_HD + lrow * S_HD + 64 * wv + 32 * j + 4 * c.h, 0);
     }
     __syncthreads();
     if (wv < 3) {  // H4: 64 -> 1; neuron on accumulator row 0 = register 0 of lanes 0..31
       f32x16 acc[1][1];
-      job_compute<1, 1>(c, ST_H4, wv, acc, lds + O_HD, S_HD, 64 * wv, 0, kStages[ST_H4].k8);
+      job_compute<1, 1, ST_H4>(c, wv, acc, lds + O_HD, S_HD, 64 * wv, 0);
       if (c.h == 0 && row0 + face0 + c.f < a.B) a.out[(row0 + face0 + c.f) * 3 + wv] = acc[0][0][0];
     }
     __syncthreads();  // hd / ha regions are reused by the next face block

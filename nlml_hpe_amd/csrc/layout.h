@@ -70,7 +70,7 @@ struct Header {
   uint32_t version;
   uint32_t F;          // encoder input width
   uint32_t mode;       // NLML_MODE_*
-  uint32_t k8_e0;      // ceil(F/8)
+  uint32_t k8_e0;      // K steps of layer 0: ceil(F/64)*8 (K zero-padded to whole pairs of 32-column x slabs)
   uint32_t total16;    // blob size in 16-byte units (incl. tail pad)
   uint32_t w_off[NUM_STAGES];  // weights of stage, 16-byte units
   uint32_t b_off[NUM_STAGES];  // bias of stage, 16-byte units
@@ -98,7 +98,7 @@ constexpr int XS_STEPS = XS_COLS / 8;
 
 // LDS offsets (floats).  Lifetimes are sequential; see DESIGN.md for the overlap argument.
 constexpr int O_H1H = 0;                          // 64*516 = 33024; pass A, then pass B in place
-constexpr int O_XS = 64 * S_H1H;                  // 2 slabs x 64*36 = 4608  -> ends 37632
+constexpr int O_XS = 64 * S_H1H;                  // 3 slabs x 64*36 = 6912  -> ends 39936 (dead before LAT is written)
 constexpr int O_H2 = 0;                           // written after E1's last K loop (barrier)
 constexpr int O_H3 = 0;                           // written after E2's K loop (barrier): 64*260 = 16640
 constexpr int O_H4 = O_H3 + 64 * S_H3;            // 16640 .. 25088
@@ -109,7 +109,7 @@ constexpr int O_HB = O_HA + 32 * S_HA;            // 12416 .. 37120
 constexpr int O_HC = 0;
 constexpr int O_HD = O_HB;
 constexpr int LDS_FLOATS = 40960;                 // 160 KiB
-static_assert(O_XS + 2 * 64 * S_XS <= O_LAT, "LDS map");
+static_assert(O_XS + 3 * 64 * S_XS <= LDS_FLOATS, "LDS map");
 static_assert(O_H5 + 64 * S_H5 <= O_LAT, "LDS map");
 static_assert(O_HB + 32 * S_HB <= O_LAT, "LDS map");
 static_assert(O_LAT + 64 * S_LAT <= LDS_FLOATS, "LDS map");

@@ -39,11 +39,15 @@ inline int row_of(const JobSrc& j, int i) {
 
 }  // namespace
 
+// Layer 0's K is padded (zero weights) to whole PAIRS of x slabs (2 x XS_COLS columns), so the kernel's
+// slab loop has no partial-slab case and its two staging register sets alternate statically.
+static int e0_k8(int F) { return (F + 2 * XS_COLS - 1) / (2 * XS_COLS) * (2 * XS_STEPS); }
+
 size_t blob_bytes_for(int F) {
   size_t units = sizeof(Header) / 16;
   for (int s = 0; s < NUM_STAGES; ++s) {
     const StageDesc& d = kStages[s];
-    int k8 = (s == ST_E0) ? (F + 7) / 8 : d.k8;
+    int k8 = (s == ST_E0) ? e0_k8(F) : d.k8;
     units += (size_t)d.jobs * k8 * d.nb * 64;      // weights: float4 per lane
     units += (size_t)d.jobs * d.nb * 2 * 4;        // bias: 2 halves x 16 floats
   }
@@ -70,7 +74,7 @@ int pack_f32(int F, const float* const enc_w[6], const float* const enc_b[6],
   hdr->version = BLOB_VERSION;
   hdr->F = (uint32_t)F;
   hdr->mode = NLML_MODE_F32;
-  hdr->k8_e0 = (uint32_t)((F + 7) / 8);
+  hdr->k8_e0 = (uint32_t)e0_k8(F);
 
   const int encN[6] = {1024, 512, 256, 128, 64, 9};
   const int encK[6] = {F, 1024, 512, 256, 128, 64};
@@ -80,7 +84,7 @@ int pack_f32(int F, const float* const enc_w[6], const float* const enc_b[6],
   size_t cur = sizeof(Header) / 16;  // 16-byte units
   for (int s = 0; s < NUM_STAGES; ++s) {
     const StageDesc& d = kStages[s];
-    const int k8 = (s == ST_E0) ? (F + 7) / 8 : d.k8;
+    const int k8 = (s == ST_E0) ? e0_k8(F) : d.k8;
     const size_t job_w16 = (size_t)k8 * d.nb * 64;
     hdr->w_off[s] = (uint32_t)cur;
     hdr->job_w16[s] = (uint32_t)job_w16;
