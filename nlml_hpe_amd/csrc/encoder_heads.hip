@@ -275,9 +275,19 @@ __device__ __forceinline__ void job_store(const Ctx& c, const f32x16 (&acc)[NB][
 // ------------------------------------------------------------------------------------------
 // Layer 0, one pass: x[64,F] streamed through LDS slabs of 32 columns; this wave computes the 128
 // neurons of job `job` (4 blocks) for both face blocks.
+// n / ipd for the IPD normalisation, correctly rounded in f64 from a once-per-row reciprocal (Markstein:
+// q = n*y, r = n - q*d exactly by fma, q' = q + r*y with y = RN(1/d)): 3 multiply-adds per element instead
+// of a ~35-instruction IEEE division sequence, and the value is rounded to f32 afterwards anyway.
+__device__ __forceinline__ double div_ipd(double n, double d, double y) {
+  const double q = n * y;
+  const double r = fma(-q, d, n);
+  return fma(r, y, q);
+}
+
 struct E0Stager {
   const float *p0, *p1;       // this thread's two rows (srow, srow + 32)
-  double ref0[3], ref1[3], ipd0, ipd1;
+  double ref0[3], ref1[3], ipd0, ipd1, rcp0, rcp1;
+  double rot0[3], rot1[3];    // ref rotated to the column phase of the slab being written
   int srow, scol;
   bool live0, live1;
   unsigned nzbits0, nzbits1;   // OR of the magnitude bits of every staged value of the row
@@ -296,6 +306,7 @@ __device__ __forceinline__ void e0_stager_init(E0Stager& g, const EncArgs& a, in
   g.p1 = a.x + r1 * a.ldx;
   g.nzbits0 = g.nzbits1 = 0u;
   g.ipd0 = g.ipd1 = 1.0;
+  g.rcp0 = g.rcp1 = 1.0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) g.ref0[k] = g.ref1[k] = 0.0;
   if (NORM) {  // IPD normalisation constants of the two rows (FeatureExtractor.py:38-48,85-86), f64
@@ -309,7 +320,7 @@ __device__ __forceinline__ void e0_stager_init(E0Stager& g, const EncArgs& a, in
       const double dz = (double)p[101] - (double)p[791];
       double d = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));  // == np.linalg.norm (sqrt of an fma-chained ddot)
       if (d == 0.0) d = 1e-6;
-      if (rr) g.ipd1 = d; else g.ipd0 = d;
+      if (rr) { g.ipd1 = d; g.rcp1 = 1.0 / d; } else { g.ipd0 = d; g.rcp0 = 1.0 / d; }
     }
   }
 }
@@ -335,7 +346,9 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
     s = s < nslab ? s : nslab - 1;
     const int k = s * XS_COLS + g.scol;
     if (VEC4) {
-      const int kc = k < F ? k : F - 4;
+      // beyond F: re-read real columns of the same row; with NORM step back by a multiple of 12 columns so
+      // the (x, y, z) phase -- hence the normalised value, hence the all-zero test -- matches column k
+      const int kc = k < F ? k : (NORM ? k - 12 * ((k - F + 15) / 12) : F - 4);
       st[0] = *reinterpret_cast<const f32x4*>(g.p0 + kc);
       st[1] = *reinterpret_cast<const f32x4*>(g.p1 + kc);
     } else {
@@ -351,33 +364,58 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
   // return finite values of the same row, and 0 * finite contributes exactly 0.  The "row is all zero"
   // test is an OR of the magnitude bits (one v_and_or per value, no compare chains); clamped duplicates
   // repeat real columns, and the OR is idempotent.
-  auto lwrite = [&](int s, int buf_off, f32x4 (&st)[2]) {
+  // The staging of one slab is cut into pieces that each fit the shadow of one MFMA (64 cycles) and are
+  // dropped into consecutive gaps of the K steps: 8 x normalise-one-element (NORM only), then the write.
+  auto lw_begin = [&](f32x4 (&st)[2]) {
     asm volatile("" : "+v"(st[0]), "+v"(st[1]));   // consumers of the loaded values stay where written
-    if (NORM) {
-      const int k = (s < nslab ? s : nslab - 1) * XS_COLS + g.scol;
-      int cidx = (k < F ? k : F - 4) % 3;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {  // explicit selects: a runtime-indexed array would live in scratch
-        const double r0 = cidx == 0 ? g.ref0[0] : (cidx == 1 ? g.ref0[1] : g.ref0[2]);
-        const double r1 = cidx == 0 ? g.ref1[0] : (cidx == 1 ? g.ref1[1] : g.ref1[2]);
-        st[0][e] = (float)(((double)st[0][e] - r0) / g.ipd0);
-        st[1][e] = (float)(((double)st[1][e] - r1) / g.ipd1);
-        cidx = (cidx == 2) ? 0 : cidx + 1;
-      }
-    }
+  };
+  // rot0/rot1: the row's reference coordinates in the order this thread's 4 columns of the CURRENT write
+  // slab need them (element e uses slot e % 3); lw_rotate() steps them to the next slab (a slab is 32
+  // columns, 32 mod 3 = 2), so no modulo or select sits in the per-element piece.
+  auto lw_norm = [&](f32x4 (&st)[2], int row, int e) {   // row, e static
+    const double r = row ? g.rot1[e % 3] : g.rot0[e % 3];
+    st[row][e] = (float)div_ipd((double)st[row][e] - r, row ? g.ipd1 : g.ipd0, row ? g.rcp1 : g.rcp0);
+  };
+  auto lw_rotate = [&]() {   // (a, b, c) <- (c, a, b): column offset +32 == +2 (mod 3)
+    const double a0 = g.rot0[0], b0 = g.rot0[1], a1 = g.rot1[0], b1 = g.rot1[1];
+    g.rot0[0] = g.rot0[2]; g.rot0[1] = a0; g.rot0[2] = b0;
+    g.rot1[0] = g.rot1[2]; g.rot1[1] = a1; g.rot1[2] = b1;
+  };
+  auto lw_finish = [&](int buf_off, f32x4 (&st)[2], bool real_slab) {
+    // (the clamped extra slabs staged at the end of a pass are never read and do not count)
+    const unsigned m = real_slab ? 0x7fffffffu : 0u;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      g.nzbits0 |= __float_as_uint(st[0][e]) & 0x7fffffffu;
-      g.nzbits1 |= __float_as_uint(st[1][e]) & 0x7fffffffu;
+      g.nzbits0 |= __float_as_uint(st[0][e]) & m;
+      g.nzbits1 |= __float_as_uint(st[1][e]) & m;
     }
     float* d = xs + buf_off;
     *reinterpret_cast<f32x4*>(d + g.srow * S_XS + g.scol) = st[0];
     *reinterpret_cast<f32x4*>(d + (g.srow + 32) * S_XS + g.scol) = st[1];
   };
+  auto lwrite = [&](int s, int buf_off, f32x4 (&st)[2]) {   // un-pipelined form (prologue only)
+    lw_begin(st);
+    if (NORM) {
+#pragma unroll
+      for (int row = 0; row < 2; ++row)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lw_norm(st, row, e);
+      lw_rotate();
+    }
+    lw_finish(buf_off, st, true);
+  };
 
   load_bias<NB, NFB>(acc, c.blob4 + c.hdr->b_off[ST_E0] + job * (NB * 8), c.h);
   const f32x4* w = c.blob4 + c.hdr->w_off[ST_E0] + (size_t)job * c.hdr->job_w16[ST_E0] + c.lane;
 
+  if (NORM) {  // phase of slab 0: this thread's first column is scol, element e is column scol + e
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int cc = (g.scol + t) % 3;
+      g.rot0[t] = cc == 0 ? g.ref0[0] : (cc == 1 ? g.ref0[1] : g.ref0[2]);
+      g.rot1[t] = cc == 0 ? g.ref1[0] : (cc == 1 ? g.ref1[1] : g.ref1[2]);
+    }
+  }
   f32x4 setA[2], setB[2];
   gload(0, setA);
   gload(1, setB);
@@ -419,8 +457,12 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
                                          ? *reinterpret_cast<const f32x4*>(xrow + fb * (32 * S_XS) + 8 * (kk + 1))
                                          : *reinterpret_cast<const f32x4*>(xnext + fb * (32 * S_XS));
           },
-          [&](int j) {
-            if (kk == 2 && j == 1) lwrite(s + 2, o_wr, wrset);   // static condition
+          [&](int j) {   // (kk, j) are static: slab s+2's staging, one piece per gap
+            if (kk == 1 && j == 0) lw_begin(wrset);
+            if (NORM && kk == 1) lw_norm(wrset, 0, j);
+            if (NORM && kk == 2) lw_norm(wrset, 1, j);
+            if (NORM && kk == 3 && j == 0) lw_rotate();
+            if (kk == 3 && j == 0) lw_finish(o_wr, wrset, s + 2 < nslab);
           });
     }
     __syncthreads();

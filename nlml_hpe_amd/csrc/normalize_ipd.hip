@@ -7,14 +7,23 @@
 //
 // One wave per face: a face is 1404 f32 = 351 float4, read and written as fully coalesced
 // 16-B-per-lane accesses (6 wave-instructions each way).  Algorithmic bytes per face:
-// 5616 read + 5616 written = 11,232 B.  The f64 subtract+divide (one true IEEE division per
-// element, needed for bit-exactness) hides under the stream.
+// 5616 read + 5616 written = 11,232 B.  The f64 subtract + correctly-rounded divide (reciprocal +
+// two fma corrections per element) hides under the stream.
 #include <hip/hip_runtime.h>
 
 #include "../../include/nlml_hpe.h"
 #include "abi_internal.h"
 
 namespace nlml {
+
+// n / d correctly rounded in f64 from y = RN(1/d) (Markstein): q = n*y, r = n - q*d exactly by fma,
+// q' = q + r*y.  Same routine as the fused kernel's staging (encoder_heads.hip), so K1 -> K2 and the fused
+// path are bit-identical; 3 multiply-adds per element instead of an IEEE division sequence.
+__device__ __forceinline__ double div_ipd(double n, double d, double y) {
+  const double q = n * y;
+  const double r = fma(-q, d, n);
+  return fma(r, y, q);
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -38,6 +47,7 @@ __global__ __launch_bounds__(256) void normalize_ipd_kernel(const float* __restr
     ipd = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
     if (ipd == 0.0) ipd = 1e-6;
   }
+  const double rcp = 1.0 / ipd;
   bool nz = false;
 #pragma unroll
   for (int it = 0; it < 6; ++it) {
@@ -48,7 +58,7 @@ __global__ __launch_bounds__(256) void normalize_ipd_kernel(const float* __restr
         int c = (4 * i) % 3;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = (float)(((double)v[e] - ref[c]) / ipd);
+          v[e] = (float)div_ipd((double)v[e] - ref[c], ipd, rcp);
           c = (c == 2) ? 0 : c + 1;
         }
       }

@@ -312,3 +312,34 @@ def test_entry_points_run(repo_root, device, tmp_path, capsys):
             assert res.stdout.count("Estimated yaw in degree") == 3
     out = np.load(tmp_path / "p.npz")
     assert out["smoothed_deg"].shape == (90, 64, 3) and np.isfinite(out["endpoints"]).all()
+
+
+def test_normalise_full_batch_bitexact(device):
+    """BASELINE size: 65,536 faces = 92 M elements.  The kernels divide through a reciprocal with two fma
+    corrections (correctly rounded in f64, then one rounding to f32); this checks every element against
+    the C oracle's true IEEE division, and the fused path against K1 -> K2."""
+    from oracle import c_oracle as CO
+    raw = synth.raw_landmarks(65536, seed=3)
+    raw[::97] *= np.float32(1e-3)
+    raw[1::97] *= np.float32(1920.0)
+    ref = CO.normalize_ipd(raw, True)
+    out = ops.normalize_ipd(torch.from_numpy(raw).to(device), True).cpu().numpy()
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+def test_fused_valid_mask_edge_cases(head_sds, device):
+    """A face whose 468 landmarks all coincide normalises to an all-zero row ("no face", FeatureExtractor.py:105-106)
+    even though the raw landmarks are non-zero; tiles that are partially filled; B not a multiple of 64."""
+    sd = synth.encoder_state_dict(1404, seed=0)
+    blob = _blob(sd, head_sds, device)
+    raw = synth.raw_landmarks(131, seed=17)
+    raw[3] = np.array([0.25, 0.5, 0.75], np.float32)      # all landmarks identical, x != y != z
+    raw[64] = 0.0
+    raw[130] = np.array([0.1, 0.1, 0.1], np.float32)
+    rt = torch.from_numpy(raw).to(device)
+    feats, v1 = ops.normalize_ipd(rt, True, return_valid=True)
+    pose, v2 = ops.landmarks_to_pose(rt, blob, True, return_valid=True)
+    ref_valid = ~FN.no_face_mask(FN.normalize_ipd(raw, True))
+    assert not ref_valid[3] and not ref_valid[64] and not ref_valid[130] and ref_valid.sum() == 128
+    assert np.array_equal(v1.cpu().numpy(), ref_valid) and np.array_equal(v2.cpu().numpy(), ref_valid)
+    assert torch.equal(pose, ops.encoder_heads_fwd(feats, blob, 1404))
