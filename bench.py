@@ -77,6 +77,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # NLML_BENCH_REHEARSAL=1: exercise the N>1 code path on a box with fewer GPUs than ranks (gloo instead of
+    # RCCL, ranks share devices).  For checking the plumbing only -- never a measurement.
+    rehearsal = os.environ.get("NLML_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -87,7 +92,10 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist_mod.init_process_group(backend="gloo")
+        else:
+            dist_mod.init_process_group(backend="nccl", device_id=dev)
         dist = dist_mod
 
     F, B = 1404, args.batch
@@ -155,7 +163,8 @@ def main():
         rec = {
             "metric": "faces_per_sec", "value": value, "unit": "faces/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: gloo, shared devices -- not a measurement)",
             "config": {"workload": f"landmarks->pose, batch {B}/GPU, F=1404 (468x3 landmarks), encoder+3 heads fused HIP forward, "
                                    f"f32 parity mode, path={args.path}",
                        "faces_per_gpu": B, "F": F, "path": args.path, "seeds": {"encoder": 0, "landmarks": "1+rank"},

@@ -284,10 +284,25 @@ __device__ __forceinline__ double div_ipd(double n, double d, double y) {
   return fma(r, y, q);
 }
 
+// ipd = ||lm[33] - lm[263]||_2 in f64 (== np.linalg.norm: sqrt of an fma-chained ddot), 1e-6 if exactly 0
+__device__ __forceinline__ void ipd_of_row(const float* p, double& ipd, double& rcp) {
+  const double dx = (double)p[99] - (double)p[789];
+  const double dy = (double)p[100] - (double)p[790];
+  const double dz = (double)p[101] - (double)p[791];
+  double d = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
+  if (d == 0.0) d = 1e-6;
+  ipd = d;
+  rcp = 1.0 / d;
+}
+
 struct E0Stager {
   const float *p0, *p1;       // this thread's two rows (srow, srow + 32)
-  double ref0[3], ref1[3], ipd0, ipd1, rcp0, rcp1;
-  double rot0[3], rot1[3];    // ref rotated to the column phase of the slab being written
+  // scalar members only: arrays inside this struct end up in scratch memory (private stack) on hipcc 7.2,
+  // and scratch loads share the vector-memory queue with the weight prefetch
+  double ipd0, ipd1, rcp0, rcp1;
+  double r0a, r0b, r0c, r1a, r1b, r1c;   // row 0 / row 1 reference coordinates, ROTATED to the column phase
+                                         // of the slab being written: element e of the thread's 4 columns
+                                         // uses slot e % 3 (a, b, c)
   int srow, scol;
   bool live0, live1;
   unsigned nzbits0, nzbits1;   // OR of the magnitude bits of every staged value of the row
@@ -307,21 +322,10 @@ __device__ __forceinline__ void e0_stager_init(E0Stager& g, const EncArgs& a, in
   g.nzbits0 = g.nzbits1 = 0u;
   g.ipd0 = g.ipd1 = 1.0;
   g.rcp0 = g.rcp1 = 1.0;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) g.ref0[k] = g.ref1[k] = 0.0;
+  g.r0a = g.r0b = g.r0c = g.r1a = g.r1b = g.r1c = 0.0;
   if (NORM) {  // IPD normalisation constants of the two rows (FeatureExtractor.py:38-48,85-86), f64
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const float* p = rr ? g.p1 : g.p0;
-      double* ref = rr ? g.ref1 : g.ref0;
-      ref[0] = (double)p[3]; ref[1] = (double)p[4]; ref[2] = (double)p[5];       // landmark 1
-      const double dx = (double)p[99] - (double)p[789];                           // 33 vs 263
-      const double dy = (double)p[100] - (double)p[790];
-      const double dz = (double)p[101] - (double)p[791];
-      double d = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));  // == np.linalg.norm (sqrt of an fma-chained ddot)
-      if (d == 0.0) d = 1e-6;
-      if (rr) { g.ipd1 = d; g.rcp1 = 1.0 / d; } else { g.ipd0 = d; g.rcp0 = 1.0 / d; }
-    }
+    ipd_of_row(g.p0, g.ipd0, g.rcp0);
+    ipd_of_row(g.p1, g.ipd1, g.rcp1);
   }
 }
 
@@ -369,17 +373,18 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
   auto lw_begin = [&](f32x4 (&st)[2]) {
     asm volatile("" : "+v"(st[0]), "+v"(st[1]));   // consumers of the loaded values stay where written
   };
-  // rot0/rot1: the row's reference coordinates in the order this thread's 4 columns of the CURRENT write
+  // r0a..r1c: the rows' reference coordinates in the order this thread's 4 columns of the CURRENT write
   // slab need them (element e uses slot e % 3); lw_rotate() steps them to the next slab (a slab is 32
   // columns, 32 mod 3 = 2), so no modulo or select sits in the per-element piece.
   auto lw_norm = [&](f32x4 (&st)[2], int row, int e) {   // row, e static
-    const double r = row ? g.rot1[e % 3] : g.rot0[e % 3];
+    const int t = e % 3;
+    const double r = row ? (t == 0 ? g.r1a : (t == 1 ? g.r1b : g.r1c)) : (t == 0 ? g.r0a : (t == 1 ? g.r0b : g.r0c));
     st[row][e] = (float)div_ipd((double)st[row][e] - r, row ? g.ipd1 : g.ipd0, row ? g.rcp1 : g.rcp0);
   };
   auto lw_rotate = [&]() {   // (a, b, c) <- (c, a, b): column offset +32 == +2 (mod 3)
-    const double a0 = g.rot0[0], b0 = g.rot0[1], a1 = g.rot1[0], b1 = g.rot1[1];
-    g.rot0[0] = g.rot0[2]; g.rot0[1] = a0; g.rot0[2] = b0;
-    g.rot1[0] = g.rot1[2]; g.rot1[1] = a1; g.rot1[2] = b1;
+    const double a0 = g.r0a, b0 = g.r0b, a1 = g.r1a, b1 = g.r1b;
+    g.r0a = g.r0c; g.r0b = a0; g.r0c = b0;
+    g.r1a = g.r1c; g.r1b = a1; g.r1c = b1;
   };
   auto lw_finish = [&](int buf_off, f32x4 (&st)[2], bool real_slab) {
     // (the clamped extra slabs staged at the end of a pass are never read and do not count)
@@ -408,13 +413,17 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
   load_bias<NB, NFB>(acc, c.blob4 + c.hdr->b_off[ST_E0] + job * (NB * 8), c.h);
   const f32x4* w = c.blob4 + c.hdr->w_off[ST_E0] + (size_t)job * c.hdr->job_w16[ST_E0] + c.lane;
 
-  if (NORM) {  // phase of slab 0: this thread's first column is scol, element e is column scol + e
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int cc = (g.scol + t) % 3;
-      g.rot0[t] = cc == 0 ? g.ref0[0] : (cc == 1 ? g.ref0[1] : g.ref0[2]);
-      g.rot1[t] = cc == 0 ? g.ref1[0] : (cc == 1 ? g.ref1[1] : g.ref1[2]);
-    }
+  if (NORM) {  // phase of slab 0: this thread's first column is scol, element e is column scol + e;
+               // landmark 1 (columns 3,4,5) is the reference point (FeatureExtractor.py:85-86)
+    const double x0 = (double)g.p0[3], y0 = (double)g.p0[4], z0 = (double)g.p0[5];
+    const double x1 = (double)g.p1[3], y1 = (double)g.p1[4], z1 = (double)g.p1[5];
+    const int ph = g.scol % 3;   // coordinate (0 x, 1 y, 2 z) of this thread's first column
+    g.r0a = ph == 0 ? x0 : (ph == 1 ? y0 : z0);
+    g.r0b = ph == 0 ? y0 : (ph == 1 ? z0 : x0);
+    g.r0c = ph == 0 ? z0 : (ph == 1 ? x0 : y0);
+    g.r1a = ph == 0 ? x1 : (ph == 1 ? y1 : z1);
+    g.r1b = ph == 0 ? y1 : (ph == 1 ? z1 : x1);
+    g.r1c = ph == 0 ? z1 : (ph == 1 ? x1 : y1);
   }
   f32x4 setA[2], setB[2];
   gload(0, setA);
