@@ -343,3 +343,23 @@ def test_fused_valid_mask_edge_cases(head_sds, device):
     assert not ref_valid[3] and not ref_valid[64] and not ref_valid[130] and ref_valid.sum() == 128
     assert np.array_equal(v1.cpu().numpy(), ref_valid) and np.array_equal(v2.cpu().numpy(), ref_valid)
     assert torch.equal(pose, ops.encoder_heads_fwd(feats, blob, 1404))
+
+
+def test_full_batch_65536_properties(head_sds, device):
+    """BASELINE.json size (65,536 faces, F = 1404): (i) a face's pose does not depend on where it sits in the
+    batch or on its tile neighbours (bit-exact against re-running sampled rows alone, in another order);
+    (ii) the sampled rows match the f64 oracle to 1e-4 deg; (iii) partial last tile: B-1 rows give the same bits."""
+    F, B = 1404, 65536
+    sd = synth.encoder_state_dict(F, seed=0)
+    blob = _blob(sd, head_sds, device)
+    x = synth.features(B, F, seed=42)
+    xt = torch.from_numpy(x).to(device)
+    full = ops.encoder_heads_fwd(xt, blob, F)
+    idx = synth.rng(42, 9).permutation(B)[:777]
+    sub = ops.encoder_heads_fwd(xt[torch.from_numpy(idx).to(device)], blob, F)
+    assert torch.equal(sub, full[torch.from_numpy(idx).to(device)])
+    ref = EH.forward_numpy(x[idx], EH.Params(sd, head_sds), np.float64)
+    err = np.degrees(np.abs(sub.cpu().numpy() - ref).max())
+    _report("full_batch_sampled_vs_f64", max_abs_deg=err)
+    assert err <= POSE_TOL_DEG
+    assert torch.equal(ops.encoder_heads_fwd(xt[:B - 1], blob, F), full[:B - 1])
