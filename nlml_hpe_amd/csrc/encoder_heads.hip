@@ -57,7 +57,7 @@ struct EncArgs {
 
 template <int ACT>
 __device__ __forceinline__ float activate(float v) {
-  if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+  if (ACT == ACT_RELU) return v < 0.0f ? 0.0f : v;   // NaN propagates like torch.relu (fmaxf would swallow it)
   if (ACT == ACT_TANH) return tanhf(v);
   return v;
 }

@@ -76,7 +76,7 @@ void oracle_encoder_heads_f32(const float* x, int64_t B, int F, const float* con
         linear_row(a, enc_w[l], enc_b[l], K, N, c, order);
         if (l == 4 && pre_tanh) memcpy(pre_tanh + r * 64, c, sizeof(float) * 64);
         for (int n = 0; n < N; ++n)
-          a[n] = (l < 4) ? fmaxf(c[n], 0.0f) : (l == 4 ? tanhf(c[n]) : c[n]);   /* ReLU x4, Tanh, none */
+          a[n] = (l < 4) ? (c[n] < 0.0f ? 0.0f : c[n]) : (l == 4 ? tanhf(c[n]) : c[n]);   /* ReLU x4 (NaN propagates, like torch.relu), Tanh, none */
         K = N;
       }
       float lat[9];
@@ -88,7 +88,7 @@ void oracle_encoder_heads_f32(const float* x, int64_t B, int F, const float* con
         for (int l = 0; l < 5; ++l) {
           const int N = HN[l + 1];
           linear_row(a, head_w[g * 5 + l], head_b[g * 5 + l], Kh, N, c, order);
-          for (int n = 0; n < N; ++n) a[n] = (l < 4) ? fmaxf(c[n], 0.0f) : c[n];
+          for (int n = 0; n < N; ++n) a[n] = (l < 4) ? (c[n] < 0.0f ? 0.0f : c[n]) : c[n];
           Kh = N;
         }
         out[r * 3 + g] = a[0];

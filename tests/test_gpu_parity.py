@@ -363,3 +363,51 @@ def test_full_batch_65536_properties(head_sds, device):
     _report("full_batch_sampled_vs_f64", max_abs_deg=err)
     assert err <= POSE_TOL_DEG
     assert torch.equal(ops.encoder_heads_fwd(xt[:B - 1], blob, F), full[:B - 1])
+
+
+def test_nan_and_inf_stay_in_their_face(head_sds, device):
+    """Faces are MFMA columns: a NaN/Inf face must not leak into its tile neighbours (the reference's rows are
+    independent, NLML_HPE_Model_Builder.py:55-68), including through the zero-padded K columns."""
+    F = 1404
+    sd = synth.encoder_state_dict(F, seed=0)
+    blob = _blob(sd, head_sds, device)
+    x = synth.features(200, F, seed=23)
+    clean = ops.encoder_heads_fwd(torch.from_numpy(x).to(device), blob, F)
+    bad = x.copy()
+    bad[5, 100] = np.nan
+    bad[70, 1403] = np.inf            # last real column: its clamped re-read feeds the padded K columns
+    bad[133, 0] = -np.inf
+    out = ops.encoder_heads_fwd(torch.from_numpy(bad).to(device), blob, F)
+    rows = torch.ones(200, dtype=torch.bool, device=device)
+    rows[[5, 70, 133]] = False
+    assert torch.equal(out[rows], clean[rows])
+    assert not torch.isfinite(out[5]).all() and not torch.isfinite(out[70]).all() and not torch.isfinite(out[133]).all()
+
+
+def test_launches_are_graph_capturable(head_sds, device):
+    """The launch functions allocate nothing and never synchronise, so a whole tick (fused forward + video
+    post-processing) can be captured into a hipGraph and replayed."""
+    from nlml_hpe_amd.model import HIPPoseModel
+    sd = synth.encoder_state_dict(1404, seed=0)
+    model = HIPPoseModel(sd, head_sds, device=device)
+    S = 64
+    raw = torch.from_numpy(synth.raw_landmarks(S, seed=3)).to(device)
+    eager = model.from_landmarks(raw, True).clone()
+    static_in = raw.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            model.from_landmarks(static_in, True)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_out = model.from_landmarks(static_in, True)
+    static_in.copy_(torch.from_numpy(synth.raw_landmarks(S, seed=4)).to(device))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, model.from_landmarks(static_in, True))
+    static_in.copy_(raw)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, eager)
