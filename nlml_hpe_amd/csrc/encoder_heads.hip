@@ -452,7 +452,9 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
   // slab s+2.  o_cur / o_next / o_wr: LDS offsets of the buffers of slabs s, s+1, s+2 (rotated by the caller,
   // so no modulo-3 arithmetic sits between the MFMAs).
   auto slab = [&](int s, int o_cur, int o_next, int o_wr, f32x4 (&ld)[2], f32x4 (&wrset)[2]) {
+#ifndef EXP_NO_STAGE
     gload(s + 3, ld);
+#endif
     const float* xrow = xs + o_cur + lane_off;
     const float* xnext = xs + o_next + lane_off;
 #pragma unroll
@@ -467,6 +469,9 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
                                          : *reinterpret_cast<const f32x4*>(xnext + fb * (32 * S_XS));
           },
           [&](int j) {   // (kk, j) are static: slab s+2's staging, one piece per gap
+#ifdef EXP_NO_STAGE
+            return;
+#endif
             if (kk == 1 && j == 0) lw_begin(wrset);
             if (NORM && kk == 1) lw_norm(wrset, 0, j);
             if (NORM && kk == 2) lw_norm(wrset, 1, j);
@@ -474,7 +479,9 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
             if (kk == 3 && j == 0) lw_finish(o_wr, wrset, s + 2 < nslab);
           });
     }
+#ifndef EXP_NO_BAR
     __syncthreads();
+#endif
   };
   // nslab is even (pack.cpp pads K to whole PAIRS of slabs): the two register sets alternate statically
   int o0 = 0, o1 = SLAB, o2 = 2 * SLAB;   // buffers of slabs s, s+1, s+2
