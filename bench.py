@@ -258,7 +258,7 @@ def extra_workloads(ops, synth, weights, dev, heads, blob, raw, feats, B):
                                  "f64_frac": N * TUCKER_FLOP_PER_EVAL / ms / 1e9 / PEAK_F64_TFLOPS, "n": N}
     # TD end-to-end (TD_Tester.Test): device-side lock-step Powell, one minimisation per face
     from oracle import tucker as TK    # test-infra helper only used to synthesise grid faces (inputs), not measured
-    idx = synth.tucker_grid_indices(1024, seed=2)
+    idx = synth.tucker_grid_indices(4096, seed=2)     # BASELINE.json config 3: 4,096 faces
     Xg = np.stack([TK.grid_reconstruction(art["W"], art["U_id"][i], art["U_yaw"][j], art["U_pitch"][k], art["U_roll"][l])
                    for i, j, k, l in idx])
     Xg = (Xg.astype(np.float64) + 1e-3 * synth.rng(2, 77).standard_normal(Xg.shape)).astype(np.float32)

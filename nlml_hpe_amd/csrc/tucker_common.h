@@ -1,19 +1,27 @@
 // tucker_common.h -- the shared body of K3 (tucker_objective.hip) and of every round of the
-// device-side Powell minimiser (tucker_powell.hip): EV objective evaluations by one workgroup.
+// device-side Powell minimiser (tucker_powell.hip): EV = 16 objective evaluations by one workgroup on
+// the f64 matrix cores.
 //
 //   f-vectors   f32(a*cos(b*w+c)+d) in f64                      (TD_Tester.py:25-28,:36-43)
-//   c[q][e]     = ((u_i * f_yj) * f_pk) * f_rl, q = ((i*3+j)*3+k)*3+l, in LDS
-//   x_hat[m]    = sum_q c[q] * Wm[q][m]   one fma chain per (evaluation, column), q ascending   (:46)
-//   err         = 0.5 * sum_m (x[m]-x_hat[m])^2   fixed-order reduction                         (:49)
+//   c[q][e]     = ((u_i * f_yj) * f_pk) * f_rl, q = ((i*3+j)*3+k)*3+l, in LDS (row 135 = 0 pads K to 136)
+//   x_hat[e][m] = sum_q c[q][e] * Wm[q][m]     D[eval][column] += A[eval][q] * B[q][column] on
+//                 v_mfma_f64_16x16x4_f64, q ascending (one fma chain per output)                 (:46)
+//   err[e]      = 0.5 * sum_m (x[m]-x_hat[m])^2   fixed-order reduction                          (:49)
 //
-// Workgroup = TNT (512) threads; thread t owns columns t, t+512, t+1024 (< 1404) for all EV = 8
-// evaluations: 24 f64 accumulators.  Per row q of Wm the block reads the row once from L2 (coalesced
-// dwords, f32 -> f64) and the 8 coefficients as an LDS broadcast, then issues 24 v_fma_f64: Wm
-// traffic (758 KB per pass) is amortised over the 8 evaluations.  8 waves per workgroup and 2
-// workgroups per CU give the 16 waves that hide the L2 latency of the dependent row loads.
+// Workgroup = 512 threads = 8 waves; the 1404 columns are 88 blocks of 16 and wave w owns blocks
+// 11w .. 11w+10 (44 f64 accumulators per lane).  Per K step of 4 a wave reads its A fragment (16
+// evaluations x 4 coefficients) from LDS once and, for each of its 11 blocks, one dword per lane of Wm
+// (4 rows x 64 B, f32 -> f64 in the register) -- each row of Wm is read once per workgroup, i.e.
+// once per 16 evaluations.  One MFMA (64 cycles) replaces 16 v_fma_f64 wave-instructions, so the
+// loads, conversions and LDS reads hide in its shadow instead of competing for issue slots
+// (the VALU form of this kernel reached 29 % of the f64 peak).
+//
+// MFMA operand / result maps (f64 16x16x4, cdna_hip_programming.md section 3): lane l supplies
+// A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; result register r of lane l is D[(l>>4) + 4r][l&15].
 //
 // Reduction order (the C oracle's device_order mode replays it bit for bit):
-//   thread: fma chain over its columns in ascending order; wave: xor butterfly, offsets 32..1;
+//   lane:  for each of its 4 evaluations, fma chain over its 11 columns in ascending block order;
+//   wave:  xor butterfly over the 16 lanes of a column group, offsets 1, 2, 4, 8;
 //   block: ((w0+w1)+(w2+w3)) + ((w4+w5)+(w6+w7)); then * 0.5.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -22,74 +30,106 @@
 
 namespace nlml {
 
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
 constexpr int TQ = NLML_TUCKER_Q;       // 135 rows of Wm
 constexpr int TM = NLML_F_REFERENCE;    // 1404 columns
-constexpr int EV = 8;                   // evaluations per workgroup
+constexpr int EV = 16;                  // evaluations per workgroup = MFMA rows
 constexpr int TNT = 512;                // threads per workgroup
-constexpr int CPT = (TM + TNT - 1) / TNT;  // 3 columns per thread
 constexpr int TNW = TNT / 64;           // 8 waves
+constexpr int TQS = (TQ + 3) / 4;       // 34 K steps of 4 (K padded to 136)
+constexpr int MBW = 11;                 // 16-column blocks per wave: 8 * 11 * 16 = 1408 >= 1404
+constexpr int TRING = 3;                // Wm prefetch ring (K steps)
 
 struct TuckerShared {
-  double coef[TQ][EV];
+  double coef[TQS * 4][EV];   // [q][evaluation]; row 135 is zero
   double fvec[EV][3][3];
   double red[TNW][EV];
 };
 
-// par: LDS or global, EV rows of 8 doubles (w_y, w_p, w_r, u_id[5]).  cp4: this thread's cosine row
-// (threads < 72 only).  Leaves acc[e][j] = x_hat of evaluation e at column tid + TNT*j.
+// par(e, k): parameter k (w_y, w_p, w_r, u_id[5]) of evaluation e.  cp4: this thread's cosine row
+// (threads < 144 only).  Leaves acc[mb][r] = x_hat of evaluation (lane>>4) + 4r at column
+// 16*(11*wave + mb) + (lane&15).
 template <typename ParT>
 __device__ __forceinline__ void tucker_xhat(TuckerShared& sh, const float* __restrict__ Wm, const ParT& par,
-                                            const double (&cp4)[4], int tid, double (&acc)[EV][CPT]) {
+                                            const double (&cp4)[4], int tid, f64x4 (&acc)[MBW]) {
   if (tid < EV * 9) {
     const int e = tid / 9, a = (tid % 9) / 3;
     const double v = cp4[0] * cos(cp4[1] * par(e, a) + cp4[2]) + cp4[3];
     sh.fvec[e][a][tid % 3] = (double)(float)v;                     // .astype(np.float32), :37,40,43
   }
   __syncthreads();
-  for (int i = tid; i < TQ * EV; i += TNT) {
+  for (int i = tid; i < TQS * 4 * EV; i += TNT) {
     const int q = i / EV, e = i % EV;
     const int ui = q / 27, j = (q / 9) % 3, k = (q / 3) % 3, l = q % 3;
-    sh.coef[q][e] = ((par(e, 3 + ui) * sh.fvec[e][0][j]) * sh.fvec[e][1][k]) * sh.fvec[e][2][l];
+    sh.coef[q][e] = q < TQ ? ((par(e, 3 + ui) * sh.fvec[e][0][j]) * sh.fvec[e][1][k]) * sh.fvec[e][2][l] : 0.0;
   }
   __syncthreads();
+
+  const int lane = tid & 63, wv = tid >> 6;
+  const int kq = lane >> 4, col = lane & 15;
+  // column of this lane in block mb: 16*(11*wv + mb) + col.  One base pointer + immediate offsets (64 B per
+  // block); only the very last block (wave 7, block 10) reaches past column 1403: those lanes re-read 1403
+  // (their x_hat is never used).
+  const float* wbase = Wm + 16 * (MBW * wv) + col;
+  const int last_off = (16 * (MBW * wv + MBW - 1) + col < TM) ? 16 * (MBW - 1) : (TM - 1) - (16 * MBW * wv + col);
+  auto woff = [&](int mb) { return mb < MBW - 1 ? 16 * mb : last_off; };
 #pragma unroll
-  for (int e = 0; e < EV; ++e)
+  for (int mb = 0; mb < MBW; ++mb) acc[mb] = f64x4{0.0, 0.0, 0.0, 0.0};
+  auto row_off = [&](int qs) {   // K step qs reads row 4*qs + kq; the padding row 135 re-reads row 134 (coefficient 0)
+    const int q = 4 * qs + kq;
+    return (size_t)(q < TQ ? q : TQ - 1) * TM;
+  };
+  float wr[TRING][MBW];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) acc[e][j] = 0.0;
-  const bool last_ok = tid + TNT * (CPT - 1) < TM;
-#pragma unroll 3
-  for (int q = 0; q < TQ; ++q) {
-    const float* wr = Wm + (size_t)q * TM + tid;
-    double w[CPT];
+  for (int d = 0; d < TRING - 1; ++d) {
+    const size_t ro = row_off(d);
 #pragma unroll
-    for (int j = 0; j < CPT - 1; ++j) w[j] = (double)wr[TNT * j];
-    w[CPT - 1] = last_ok ? (double)wr[TNT * (CPT - 1)] : 0.0;
-#pragma unroll
-    for (int e = 0; e < EV; ++e) {
-      const double c = sh.coef[q][e];
-#pragma unroll
-      for (int j = 0; j < CPT; ++j) acc[e][j] = fma(c, w[j], acc[e][j]);
-    }
+    for (int mb = 0; mb < MBW; ++mb) wr[d][mb] = wbase[ro + woff(mb)];
   }
+  // 34 K steps = 11 groups of 3 + 1: ring slot = step % 3, static inside the unrolled group
+  auto step = [&](int qs, int slot, bool prefetch) {
+    if (prefetch) {
+      const size_t ro = row_off(qs + TRING - 1 < TQS ? qs + TRING - 1 : TQS - 1);
+#pragma unroll
+      for (int mb = 0; mb < MBW; ++mb) wr[(slot + TRING - 1) % TRING][mb] = wbase[ro + woff(mb)];
+    }
+    const double a = sh.coef[4 * qs + kq][col];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb)
+      acc[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (double)wr[slot][mb], acc[mb], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  constexpr int GROUPS = TQS / TRING, TAIL = TQS % TRING;
+  for (int g = 0; g < GROUPS; ++g) {
+#pragma unroll
+    for (int r = 0; r < TRING; ++r) step(g * TRING + r, r, true);
+  }
+#pragma unroll
+  for (int r = 0; r < TAIL; ++r) step(GROUPS * TRING + r, r, false);
 }
 
-// Residual norms of the EV evaluations; xv[e][j] = x of evaluation e at this thread's column j.
-// After the call (and the barrier inside) every thread may read err_of(e).
-__device__ __forceinline__ void tucker_residual(TuckerShared& sh, const float (&xv)[EV][CPT],
-                                                const double (&acc)[EV][CPT], int tid) {
+// Residual norms of the 16 evaluations.  xv[mb][r] = x of evaluation (lane>>4) + 4r at this lane's column of
+// block mb.  After the call (barrier inside) tucker_err(e) is valid for every thread.
+__device__ __forceinline__ void tucker_residual(TuckerShared& sh, const float (&xv)[MBW][4], const f64x4 (&acc)[MBW],
+                                                int tid) {
+  const int lane = tid & 63, wv = tid >> 6, col = lane & 15;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int e = 0; e < EV; ++e) {
-    double s = 0.0;
+  for (int mb = 0; mb < MBW; ++mb) {
+    const bool live = 16 * (MBW * wv + mb) + col < TM;
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      if (tid + TNT * j < TM) {
-        const double r = (double)xv[e][j] - acc[e][j];
-        s = fma(r, r, s);
-      }
+    for (int r = 0; r < 4; ++r) {
+      const double d = (double)xv[mb][r] - acc[mb][r];
+      s[r] = live ? fma(d, d, s[r]) : s[r];
     }
+  }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if ((tid & 63) == 0) sh.red[tid >> 6][e] = s;
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) s[r] += __shfl_xor(s[r], off, 64);
+    if (col == 0) sh.red[wv][(lane >> 4) + 4 * r] = s[r];
   }
   __syncthreads();
 }

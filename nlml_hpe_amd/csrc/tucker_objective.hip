@@ -1,9 +1,9 @@
-// tucker_objective.hip -- K3: batched Tucker-einsum objective in f64.
+// tucker_objective.hip -- K3: batched Tucker-einsum objective in f64 on the matrix cores.
 //
 // Replaces objective() (TD_Tester.py:31-58) for N face-evaluations at once, restated as
 // c = u (x) f_y (x) f_p (x) f_r (135 f64 coefficients per evaluation) and x_hat = c^T Wm,
 // Wm = W.reshape(135,1404): a [N,135] x [135,1404] f64 GEMM fused with the residual norm.
-// The per-workgroup body (8 evaluations, one pass over Wm) is tucker_common.h.
+// The per-workgroup body (16 evaluations, one pass over Wm, v_mfma_f64_16x16x4_f64) is tucker_common.h.
 #include <hip/hip_runtime.h>
 
 #include "abi_internal.h"
@@ -19,7 +19,7 @@ struct GlobalPar {
   }
 };
 
-__global__ __launch_bounds__(TNT, 4) void tucker_objective_kernel(
+__global__ __launch_bounds__(TNT, 2) void tucker_objective_kernel(
     const float* __restrict__ Wm, const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ x_index,
     const double* __restrict__ params, const double* __restrict__ cosp, int64_t N, double* __restrict__ err,
     double* __restrict__ x_hat) {
@@ -33,22 +33,24 @@ __global__ __launch_bounds__(TNT, 4) void tucker_objective_kernel(
     cp4[0] = c4[0]; cp4[1] = c4[1]; cp4[2] = c4[2]; cp4[3] = c4[3];
   }
   GlobalPar par{params + e0 * 8, N - e0};
-  double acc[EV][CPT];
+  f64x4 acc[MBW];
   tucker_xhat(sh, Wm, par, cp4, tid, acc);
 
-  float xv[EV][CPT];
+  const int lane = tid & 63, wv = tid >> 6, col = lane & 15;
+  float xv[MBW][4];
 #pragma unroll
-  for (int e = 0; e < EV; ++e) {
+  for (int r = 0; r < 4; ++r) {
+    const int e = (lane >> 4) + 4 * r;
     const int64_t n = e0 + e;
     const bool live = n < N;
     const int64_t nn = live ? n : N - 1;
     const int64_t xr = x_index ? (int64_t)x_index[nn] : nn;
     const float* xp = x + xr * ldx;
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      const int m = tid + TNT * j;
-      xv[e][j] = m < TM ? xp[m] : 0.f;
-      if (x_hat && live && m < TM) x_hat[n * TM + m] = acc[e][j];
+    for (int mb = 0; mb < MBW; ++mb) {
+      const int m = 16 * (MBW * wv + mb) + col;
+      xv[mb][r] = xp[m < TM ? m : TM - 1];
+      if (x_hat && live && m < TM) x_hat[n * TM + m] = acc[mb][r];
     }
   }
   tucker_residual(sh, xv, acc, tid);

@@ -1,17 +1,16 @@
 // tucker_powell.hip -- TD end-to-end on device: lock-step Powell minimisation of the Tucker objective.
 //
 // Replaces Test() (TD_Tester.py:162-199) = scipy Powell over objective() (:31-58), 2-4 s per face on
-// the reference's CPU path.  One workgroup owns EV = 8 faces for the whole minimisation:
+// the reference's CPU path.  One workgroup owns EV = 16 faces for the whole minimisation:
 //
-//   repeat:  lanes 0..7 each resume their face's Powell/Brent state machine (powell.h) with the
+//   repeat:  lanes 0..15 each resume their face's Powell/Brent state machine (powell.h) with the
 //            objective value of the previous round and publish the next trial point (8 doubles);
-//            all 512 threads then evaluate the 8 objectives together exactly as K3 does
-//            (tucker_common.h: one pass over Wm from L2 shared by the 8 evaluations);
-//   until all 8 machines have finished.
+//            all 512 threads then evaluate the 16 objectives together exactly as K3 does
+//            (tucker_common.h: one pass over Wm from L2 shared by the 16 evaluations, f64 MFMA);
+//   until all 16 machines have finished.
 //
 // Faces are independent, so there is no grid-level synchronisation: a workgroup runs as many
-// rounds as its slowest face needs (1.4k-7k).  The face's feature row is loaded once and stays in
-// registers; the machine state lives in LDS.  Every round costs one Wm pass (758 KB from L2) per 8
+// rounds as its slowest face needs (1.4k-7k).  The machine state lives in LDS.  Every round costs one Wm pass (758 KB from L2) per 8
 // faces: ~383.7 kFLOP (f64) per face-evaluation, the same roofline as K3.
 #include <hip/hip_runtime.h>
 
@@ -20,6 +19,10 @@
 #include "tucker_common.h"
 
 namespace nlml {
+
+// The state machine is a large switch; inlined into the kernel it inflates the register demand of the
+// whole function (spills in the MFMA loop).  As a real call its registers are its own.
+__device__ __attribute__((noinline)) bool powell_step_call(PowellState* s, double f) { return powell_step(*s, f); }
 
 struct LdsPar {
   const double (*p)[PW_N];
@@ -38,18 +41,15 @@ __global__ __launch_bounds__(TNT, 2) void tucker_powell_kernel(
   const int tid = threadIdx.x;
   const int64_t e0 = (int64_t)blockIdx.x * EV;
 
-  // this thread's columns of the 8 feature rows, kept for the whole minimisation
-  float xv[EV][CPT];
+  // this lane's 4 evaluations x 11 columns of the feature rows are re-read from L2 every round (44 dwords
+  // per lane against 374 of Wm): holding them across the state-machine code costs more in spills
+  const int lane = tid & 63, wv = tid >> 6, col = lane & 15;
+  const float* xrow[4];
 #pragma unroll
-  for (int e = 0; e < EV; ++e) {
-    int64_t n = e0 + e;
+  for (int r = 0; r < 4; ++r) {
+    int64_t n = e0 + (lane >> 4) + 4 * r;
     n = n < N ? n : N - 1;
-    const float* xp = x + n * ldx;
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      const int m = tid + TNT * j;
-      xv[e][j] = m < TM ? xp[m] : 0.f;
-    }
+    xrow[r] = x + n * ldx;
   }
   double cp4[4] = {0, 0, 0, 0};
   if (tid < EV * 9) {
@@ -57,16 +57,20 @@ __global__ __launch_bounds__(TNT, 2) void tucker_powell_kernel(
     cp4[0] = c4[0]; cp4[1] = c4[1]; cp4[2] = c4[2]; cp4[3] = c4[3];
   }
 
-  if (tid < EV) {
+  // machine e runs on lane e&1 of wave e>>1: two machines per wave, so the divergent state-machine code is at
+  // most 2-way serialised and the 8 waves step their machines concurrently (16 machines on the lanes of one
+  // wave would serialise up to 16 paths per round)
+  const int me = ((tid & 63) < 2) ? 2 * (tid >> 6) + (tid & 63) : -1;
+  if (me >= 0) {
     double z[PW_N];
-    const bool live = e0 + tid < N;
+    const bool live = e0 + me < N;
 #pragma unroll
-    for (int k = 0; k < PW_N; ++k) z[k] = (x0 && live) ? x0[(e0 + tid) * PW_N + k] : 0.0;
-    powell_init(st[tid], z);
-    const bool nd = live && powell_step(st[tid], 0.0);
-    need[tid] = nd ? 1 : 0;
+    for (int k = 0; k < PW_N; ++k) z[k] = (x0 && live) ? x0[(e0 + me) * PW_N + k] : 0.0;
+    powell_init(st[me], z);
+    const bool nd = live && powell_step_call(&st[me], 0.0);
+    need[me] = nd ? 1 : 0;
 #pragma unroll
-    for (int k = 0; k < PW_N; ++k) par[tid][k] = st[tid].xeval[k];
+    for (int k = 0; k < PW_N; ++k) par[me][k] = st[me].xeval[k];
   }
   __syncthreads();
 
@@ -77,16 +81,24 @@ __global__ __launch_bounds__(TNT, 2) void tucker_powell_kernel(
     for (int e = 0; e < EV; ++e) any |= need[e];
     if (!any) break;
 
-    double acc[EV][CPT];
+    f64x4 acc[MBW];
     tucker_xhat(sh, Wm, lp, cp4, tid, acc);
+    float xv[MBW][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int mb = 0; mb < MBW; ++mb) {
+        const int m = 16 * (MBW * wv + mb) + col;
+        xv[mb][r] = xrow[r][m < TM ? m : TM - 1];
+      }
     tucker_residual(sh, xv, acc, tid);
 
-    if (tid < EV && need[tid]) {   // resume the state machines with their objective values
-      const bool nd = powell_step(st[tid], tucker_err(sh, tid));
-      need[tid] = nd ? 1 : 0;
+    if (me >= 0 && need[me]) {   // resume the state machines with their objective values
+      const bool nd = powell_step_call(&st[me], tucker_err(sh, me));
+      need[me] = nd ? 1 : 0;
       if (nd) {
 #pragma unroll
-        for (int k = 0; k < PW_N; ++k) par[tid][k] = st[tid].xeval[k];
+        for (int k = 0; k < PW_N; ++k) par[me][k] = st[me].xeval[k];
       }
     }
     __syncthreads();

@@ -103,26 +103,24 @@ void oracle_encoder_heads_f32(const float* x, int64_t B, int F, const float* con
  * Wm f32[135,1404]; x f32[N,1404]; params f64[N,8]; cosp f64[3,3,4]; err f64[N]; xhat f64[N,1404]|NULL.
  * x_hat[m] = sum_q c[q]*Wm[q][m], q ascending in one fma chain (the HIP kernel's order). */
 /* device_order != 0: the residual is summed in the HIP kernel's order (tucker_objective.hip /
- * tucker_powell.hip): thread t of 512 owns columns t, t+512, t+1024 (fma chain), then a 64-lane xor
- * butterfly per wave (offsets 32..1), then ((w0+w1)+(w2+w3))+((w4+w5)+(w6+w7)); the result is then bit-identical to the
+ * tucker_powell.hip): the MFMA tiling's order, see residual_device_order; the result is then bit-identical to the
  * GPU's, which lets the device-side Powell run be replayed exactly on the CPU. */
 static double residual_device_order(const float* xrow, const double* acc) {
-  enum { NT = 512, CPT = 3, NW = 8 };
-  double s[NT];
-  for (int t = 0; t < NT; ++t) {
-    double v = 0.0;
-    for (int j = 0; j < CPT; ++j) {
-      const int m = t + NT * j;
-      if (m < 1404) { const double r = (double)xrow[m] - acc[m]; v = fma(r, r, v); }
+  /* tucker_common.h: 8 waves x 11 blocks of 16 columns; lane column c of wave w sums its 11 columns
+   * (fma chain, ascending block), xor butterfly over the 16 lanes (offsets 1,2,4,8), then the 8 waves. */
+  double red[8];
+  for (int w = 0; w < 8; ++w) {
+    double v[16], n[16];
+    for (int c = 0; c < 16; ++c) {
+      double s = 0.0;
+      for (int mb = 0; mb < 11; ++mb) {
+        const int m = 16 * (11 * w + mb) + c;
+        if (m < 1404) { const double r = (double)xrow[m] - acc[m]; s = fma(r, r, s); }
+      }
+      v[c] = s;
     }
-    s[t] = v;
-  }
-  double red[NW];
-  for (int w = 0; w < NW; ++w) {
-    double v[64], n[64];
-    memcpy(v, s + 64 * w, sizeof v);
-    for (int off = 32; off > 0; off >>= 1) {
-      for (int l = 0; l < 64; ++l) n[l] = v[l] + v[l ^ off];
+    for (int off = 1; off < 16; off <<= 1) {
+      for (int c = 0; c < 16; ++c) n[c] = v[c] + v[c ^ off];
       memcpy(v, n, sizeof v);
     }
     red[w] = v[0];
