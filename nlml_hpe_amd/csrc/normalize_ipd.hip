@@ -38,9 +38,17 @@ __global__ __launch_bounds__(256) void normalize_ipd_kernel(const float* __restr
   const float* p = raw + face * NLML_F_REFERENCE;
   float* o = out + face * NLML_F_REFERENCE;
 
-  double ref[3] = {0.0, 0.0, 0.0}, ipd = 1.0;
+  // all loads first (6 x 16 B per lane + the 9 reference floats), none of them depends on another:
+  // the whole face is in flight before any arithmetic starts
+  f32x4 v[6];
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int i = it * 64 + lane;
+    v[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + (i < F4 ? i : F4 - 1));
+  }
+  double rx = 0.0, ry = 0.0, rz = 0.0, ipd = 1.0;
   if (normalize) {
-    ref[0] = (double)p[3]; ref[1] = (double)p[4]; ref[2] = (double)p[5];    // nose tip, landmark 1
+    rx = (double)p[3]; ry = (double)p[4]; rz = (double)p[5];                // nose tip, landmark 1
     const double dx = (double)p[99] - (double)p[789];                        // landmark 33 - 263
     const double dy = (double)p[100] - (double)p[790];
     const double dz = (double)p[101] - (double)p[791];
@@ -48,24 +56,27 @@ __global__ __launch_bounds__(256) void normalize_ipd_kernel(const float* __restr
     if (ipd == 0.0) ipd = 1e-6;
   }
   const double rcp = 1.0 / ipd;
-  bool nz = false;
+  // element e of float4 i is column 4i+e, coordinate (4i+e) % 3; i = 64*it + lane and 256 % 3 == 1, so the phase
+  // of a lane advances by one per iteration: rotate (a, b, c) instead of taking a modulo per element
+  const int ph = (4 * lane) % 3;
+  double a = ph == 0 ? rx : (ph == 1 ? ry : rz), b = ph == 0 ? ry : (ph == 1 ? rz : rx), c = ph == 0 ? rz : (ph == 1 ? rx : ry);
+  unsigned nzbits = 0u;
 #pragma unroll
   for (int it = 0; it < 6; ++it) {
     const int i = it * 64 + lane;
+    if (normalize) {
+      v[it][0] = (float)div_ipd((double)v[it][0] - a, ipd, rcp);
+      v[it][1] = (float)div_ipd((double)v[it][1] - b, ipd, rcp);
+      v[it][2] = (float)div_ipd((double)v[it][2] - c, ipd, rcp);
+      v[it][3] = (float)div_ipd((double)v[it][3] - a, ipd, rcp);
+      const double t = a; a = b; b = c; c = t;     // next iteration: columns + 256 => phase + 1
+    }
     if (i < F4) {
-      f32x4 v = reinterpret_cast<const f32x4*>(p)[i];
-      if (normalize) {
-        int c = (4 * i) % 3;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = (float)div_ipd((double)v[e] - ref[c], ipd, rcp);
-          c = (c == 2) ? 0 : c + 1;
-        }
-      }
-      nz |= (v[0] != 0.f) | (v[1] != 0.f) | (v[2] != 0.f) | (v[3] != 0.f);
-      reinterpret_cast<f32x4*>(o)[i] = v;
+      nzbits |= (__float_as_uint(v[it][0]) | __float_as_uint(v[it][1]) | __float_as_uint(v[it][2]) | __float_as_uint(v[it][3])) & 0x7fffffffu;
+      __builtin_nontemporal_store(v[it], reinterpret_cast<f32x4*>(o) + i);
     }
   }
+  const bool nz = nzbits != 0u;
   if (valid) {
     const unsigned long long m = __ballot(nz);
     if (lane == 0) valid[face] = m ? 1 : 0;
