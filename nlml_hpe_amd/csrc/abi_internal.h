@@ -9,15 +9,19 @@ namespace nlml {
 int fail(int code, const char* msg);
 
 // pack.cpp
-size_t blob_bytes_for(int F);
-int pack_f32(int F, const float* const enc_w[6], const float* const enc_b[6],
-             const float* const head_w[3][5], const float* const head_b[3][5],
-             void* blob, size_t blob_bytes);
+size_t blob_bytes_for(int F, int mode);
+int pack_blob(int F, int mode, const float* const enc_w[6], const float* const enc_b[6],
+              const float* const head_w[3][5], const float* const head_b[3][5],
+              void* blob, size_t blob_bytes);
 
 // encoder_heads.hip
 int launch_encoder_heads_f32(const float* x, int64_t ldx, const float* raw, int normalize,
                              int64_t B, int F, const void* blob, float* out, float* latent,
                              uint8_t* valid, float* pre_tanh, unsigned long long* stamps, void* stream);
+// encoder_heads_bf16.hip (throughput mode)
+int launch_encoder_heads_bf16(const float* x, int64_t ldx, const float* raw, int normalize,
+                              int64_t B, int F, const void* blob, float* out, float* latent,
+                              uint8_t* valid, void* stream);
 // normalize_ipd.hip
 int launch_normalize_ipd(const float* raw, int64_t B, int normalize, float* out, uint8_t* valid,
                          void* stream);

@@ -114,4 +114,49 @@ static_assert(O_H5 + 64 * S_H5 <= O_LAT, "LDS map");
 static_assert(O_HB + 32 * S_HB <= O_LAT, "LDS map");
 static_assert(O_LAT + 64 * S_LAT <= LDS_FLOATS, "LDS map");
 
+// ------------------------------------------------------------------------------------------
+// bf16 throughput mode (NLML_MODE_BF16): same stages, jobs and bias format; weights are bf16 and a K step
+// is 16 (one v_mfma_f32_32x32x16_bf16 per neuron block and face block): lane l (r = l&31, h = l>>5) holds
+// the 8 weights W[32*nb + r][16s + 8h + j], j = 0..7 = 16 bytes, so offsets and job sizes keep the same
+// 16-byte units with k16 steps in place of k8 steps.  Activations live in LDS as bf16 [face][k] rows with
+// stride k+8 elements (16-byte chunks per row odd => conflict-free ds_read_b128).  Layer 0's output for 64
+// faces is 128 KB in bf16, so layer 0 runs in ONE pass (8 neuron blocks per wave) and x is read once.
+namespace bf {
+
+constexpr StageDesc kStages[NUM_STAGES] = {   // k8 field = K steps of 16 here
+    /*E0  F   ->1024 relu*/ {8, 4, 0, 0},
+    /*E1 1024-> 512 relu*/ {4, 4, 1024, 64},
+    /*E2  512-> 256 relu*/ {2, 4, 512, 32},
+    /*E3  256-> 128 relu*/ {1, 4, 256, 16},
+    /*E4  128->  64 tanh*/ {1, 2, 128, 8},
+    /*E5   64->   9 none*/ {2, 1, 64, 4},     // latent n = 3g+c on row 16g+c: 48 rows = 2 blocks
+    /*H0 3x(3->128) relu*/ {1, 12, 3, 1},
+    /*H1 3x(128->256)   */ {2, 12, 128, 8},
+    /*H2 3x(256->128)   */ {1, 12, 256, 16},
+    /*H3 3x(128->64)    */ {1, 6, 128, 8},
+    /*H4 3x(64->1)  none*/ {1, 3, 64, 4},
+};
+constexpr int XS_COLS = 64;             // x slab: 64 columns = 4 K steps of 16
+constexpr int XS_STEPS = XS_COLS / 16;
+// strides in bf16 elements
+constexpr int S_H1 = 1032, S_H2 = 520, S_H3 = 264, S_H4 = 136, S_H5 = 72, S_LAT = 72;   // LAT: 2 blocks = 64 columns
+constexpr int S_HA = 392, S_HB = 776, S_HC = 392, S_HD = 200, S_XS = 72;
+// LDS offsets in BYTES
+constexpr int O_H1 = 0;                                   // 64*1032*2 = 132096
+constexpr int O_XS = 64 * S_H1 * 2;                       // 3 slabs x 9216 -> ends 159744
+constexpr int O_H2 = 0;                                   // after barrier: 66560
+constexpr int O_H3 = 64 * S_H2 * 2;                       // 66560 .. 100352
+constexpr int O_H4 = O_H3 + 64 * S_H3 * 2;                // .. 117760
+constexpr int O_H5 = O_H4 + 64 * S_H4 * 2;                // .. 126976
+constexpr int O_LAT = 163840 - 64 * S_LAT * 2;            // 154624 .. 163840 (x slabs are dead by then)
+constexpr int O_HA = 0;                                   // 32*392*2 = 25088
+constexpr int O_HB = O_HA + 32 * S_HA * 2;                // .. 74752
+constexpr int O_HC = 0;
+constexpr int O_HD = O_HB;
+static_assert(O_XS + 3 * 64 * S_XS * 2 <= 163840, "LDS map");
+static_assert(O_H5 + 64 * S_H5 * 2 <= O_LAT, "LDS map");
+static_assert(O_HB + 32 * S_HB * 2 <= O_LAT, "LDS map");
+
+}  // namespace bf
+
 }  // namespace nlml

@@ -19,14 +19,15 @@ struct JobSrc {
   int N;            // true N
   int row0;         // first neuron of the job (for plain jobs)
   int special;      // 0: rows row0 + i;  1: E5 latent placement;  2: H4 single row
+  int lat_step;     // E5: columns reserved per head in the latent image (8 in f32 mode, 16 in bf16 mode)
 };
 
 // neuron index feeding accumulator row i (0 .. 32*nb-1) of the job, or -1 for a zero row
 inline int row_of(const JobSrc& j, int i) {
   switch (j.special) {
-    case 1: {  // E5: latent n = 3g + c lands on row 8g + c  -> head g reads columns 8g..8g+7
-      int g = i >> 3, c = i & 7;
-      return (i < 24 && c < 3) ? 3 * g + c : -1;
+    case 1: {  // E5: latent n = 3g + c lands on row step*g + c -> head g reads columns step*g .. +step-1
+      int g = i / j.lat_step, c = i % j.lat_step;
+      return (g < 3 && c < 3) ? 3 * g + c : -1;
     }
     case 2:  // H4: the single output neuron on row 0
       return i == 0 ? 0 : -1;
@@ -42,12 +43,25 @@ inline int row_of(const JobSrc& j, int i) {
 // Layer 0's K is padded (zero weights) to whole PAIRS of x slabs (2 x XS_COLS columns), so the kernel's
 // slab loop has no partial-slab case and its two staging register sets alternate statically.
 static int e0_k8(int F) { return (F + 2 * XS_COLS - 1) / (2 * XS_COLS) * (2 * XS_STEPS); }
+// bf16 mode: K steps of 16, x slabs of 64 columns, slab pairs => K padded to 128 columns
+static int e0_k16(int F) { return (F + 2 * bf::XS_COLS - 1) / (2 * bf::XS_COLS) * (2 * bf::XS_STEPS); }
 
-size_t blob_bytes_for(int F) {
+static const StageDesc& stage_of(int mode, int s) { return mode == NLML_MODE_BF16 ? bf::kStages[s] : kStages[s]; }
+static int e0_steps(int mode, int F) { return mode == NLML_MODE_BF16 ? e0_k16(F) : e0_k8(F); }
+
+// round-to-nearest-even f32 -> bf16 (NaN stays NaN)
+static uint16_t to_bf16(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+size_t blob_bytes_for(int F, int mode) {
   size_t units = sizeof(Header) / 16;
   for (int s = 0; s < NUM_STAGES; ++s) {
-    const StageDesc& d = kStages[s];
-    int k8 = (s == ST_E0) ? e0_k8(F) : d.k8;
+    const StageDesc& d = stage_of(mode, s);
+    int k8 = (s == ST_E0) ? e0_steps(mode, F) : d.k8;
     units += (size_t)d.jobs * k8 * d.nb * 64;      // weights: float4 per lane
     units += (size_t)d.jobs * d.nb * 2 * 4;        // bias: 2 halves x 16 floats
   }
@@ -55,11 +69,14 @@ size_t blob_bytes_for(int F) {
   return units * 16;
 }
 
-int pack_f32(int F, const float* const enc_w[6], const float* const enc_b[6],
-             const float* const head_w[3][5], const float* const head_b[3][5],
-             void* blob, size_t blob_bytes) {
+int pack_blob(int F, int mode, const float* const enc_w[6], const float* const enc_b[6],
+              const float* const head_w[3][5], const float* const head_b[3][5],
+              void* blob, size_t blob_bytes) {
   if (F <= 0 || !blob) return fail(NLML_E_BADARG, "pack: bad F or null blob");
-  const size_t need = blob_bytes_for(F);
+  const bool bf16 = mode == NLML_MODE_BF16;
+  const int kw = bf16 ? 16 : 8;        // K step width
+  const int per_half = kw / 2;         // k values per lane half
+  const size_t need = blob_bytes_for(F, mode);
   if (blob_bytes < need) return fail(NLML_E_BADARG, "pack: blob buffer too small");
   for (int i = 0; i < 6; ++i)
     if (!enc_w[i] || !enc_b[i]) return fail(NLML_E_BADARG, "pack: null encoder tensor");
@@ -73,8 +90,8 @@ int pack_f32(int F, const float* const enc_w[6], const float* const enc_b[6],
   hdr->magic = BLOB_MAGIC;
   hdr->version = BLOB_VERSION;
   hdr->F = (uint32_t)F;
-  hdr->mode = NLML_MODE_F32;
-  hdr->k8_e0 = (uint32_t)e0_k8(F);
+  hdr->mode = (uint32_t)mode;
+  hdr->k8_e0 = (uint32_t)e0_steps(mode, F);
 
   const int encN[6] = {1024, 512, 256, 128, 64, 9};
   const int encK[6] = {F, 1024, 512, 256, 128, 64};
@@ -83,8 +100,8 @@ int pack_f32(int F, const float* const enc_w[6], const float* const enc_b[6],
 
   size_t cur = sizeof(Header) / 16;  // 16-byte units
   for (int s = 0; s < NUM_STAGES; ++s) {
-    const StageDesc& d = kStages[s];
-    const int k8 = (s == ST_E0) ? e0_k8(F) : d.k8;
+    const StageDesc& d = stage_of(mode, s);
+    const int k8 = (s == ST_E0) ? e0_steps(mode, F) : d.k8;
     const size_t job_w16 = (size_t)k8 * d.nb * 64;
     hdr->w_off[s] = (uint32_t)cur;
     hdr->job_w16[s] = (uint32_t)job_w16;
@@ -93,6 +110,7 @@ int pack_f32(int F, const float* const enc_w[6], const float* const enc_b[6],
 
     for (int j = 0; j < d.jobs; ++j) {
       JobSrc src{};
+      src.lat_step = bf16 ? 16 : 8;
       if (s <= ST_E5) {
         src.W = enc_w[s]; src.b = enc_b[s]; src.K = encK[s]; src.N = encN[s];
         src.row0 = j * d.nb * 32;
@@ -110,10 +128,12 @@ int pack_f32(int F, const float* const enc_w[6], const float* const enc_b[6],
         for (int nb = 0; nb < d.nb; ++nb)
           for (int lane = 0; lane < 64; ++lane) {
             const int n = row_of(src, nb * 32 + (lane & 31));
-            float* dst = w + (((size_t)st * d.nb + nb) * 64 + lane) * 4;
-            for (int e = 0; e < 4; ++e) {
-              const int k = 8 * st + 4 * (lane >> 5) + e;
-              dst[e] = (n >= 0 && k < src.K) ? src.W[(size_t)n * src.K + k] : 0.0f;
+            float* dst = w + (((size_t)st * d.nb + nb) * 64 + lane) * 4;      // 16 bytes per lane
+            uint16_t* dst16 = reinterpret_cast<uint16_t*>(dst);
+            for (int e = 0; e < per_half; ++e) {
+              const int k = kw * st + per_half * (lane >> 5) + e;
+              const float v = (n >= 0 && k < src.K) ? src.W[(size_t)n * src.K + k] : 0.0f;
+              if (bf16) dst16[e] = to_bf16(v); else dst[e] = v;
             }
           }
       float* b = base + (b_off + (size_t)j * d.nb * 8) * 4;

@@ -19,6 +19,8 @@ class HIPPoseModel:
     """CombinedAnglePredictionModel (Model_Builder.py:107-126) on the fused gfx950 kernel."""
 
     def __init__(self, encoder_sd: dict, head_sds: dict, device="cuda", mode: int = _lib.MODE_F32):
+        """mode: _lib.MODE_F32 = parity mode (<= 1e-4 deg of the reference); _lib.MODE_BF16 = throughput mode
+        (bf16 weights/activations, ~0.1 deg from the reference -- never a parity result)."""
         self.input_size = weights.validate_shapes(encoder_sd, head_sds)
         self.mode = mode
         self.device = torch.device(device)

@@ -114,3 +114,41 @@ def flops_per_face(input_size: int) -> int:
     head = [3, 128, 256, 128, 64, 1]
     macs = sum(a * b for a, b in zip(enc[:-1], enc[1:])) + 3 * sum(a * b for a, b in zip(head[:-1], head[1:]))
     return 2 * macs
+
+
+def _bf16_round(a: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even f32 -> bf16 -> f32 (what v_cvt_pk_bf16_f32 and the host packer do)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)) << np.uint32(16)
+    return r.astype(np.uint32).view(np.float32)
+
+
+def forward_bf16_emulated(x: np.ndarray, p: Params) -> np.ndarray:
+    """Model of the bf16 THROUGHPUT mode (encoder_heads_bf16.hip): weights and every activation that goes
+    through LDS rounded to bf16, products and sums in f64 (the kernel accumulates in f32), bias f32.
+    Not a parity oracle for the reference -- it pins the throughput kernel's indexing and rounding points."""
+    def lin(h, w, b):
+        return h @ _bf16_round(w).T.astype(np.float64) + b.astype(np.float64)
+    h = _bf16_round(np.asarray(x, dtype=np.float32)).astype(np.float64)
+    n = len(p.enc)
+    for li, (w, b) in enumerate(p.enc):
+        h = lin(h, w, b)
+        if li < n - 2:
+            h = np.maximum(h, 0)
+        elif li == n - 2:
+            h = np.tanh(h)
+        if li < n - 1:
+            h = _bf16_round(h.astype(np.float32)).astype(np.float64)
+    latent = h
+    lat_b = _bf16_round(latent.astype(np.float32)).astype(np.float64)
+    outs, start = [], 0
+    for name, (m, nn_) in zip(HEAD_NAMES, p.matrix_dims):
+        z = lat_b[:, start:start + m * nn_]
+        start += m * nn_
+        layers = p.heads[name]
+        for li, (w, b) in enumerate(layers):
+            z = lin(z, w, b)
+            if li < len(layers) - 1:
+                z = _bf16_round(np.maximum(z, 0).astype(np.float32)).astype(np.float64)
+        outs.append(z)
+    return np.concatenate(outs, axis=1), latent
