@@ -276,9 +276,10 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const Args& a, int64_t ro
   load_bias<NB, NFB>(acc, c.blob4 + c.hdr->b_off[ST_E0] + c.wv * (NB * 8), c.h);
   const bf16x8* w = c.blob8 + c.hdr->w_off[ST_E0] + (size_t)c.wv * c.hdr->job_w16[ST_E0] + c.lane;
 
-  f32x4 setA[4], setB[4];
-  gload(0, setA);
-  gload(1, setB);
+  // ONE staging register set (16 floats per thread): slab s+2 is written in the middle of slab s and the set is
+  // refilled at once with the loads of slab s+3, which then have a whole slab (~9k cycles, weight-stream
+  // bound) to arrive.  Two sets pushed the NORM variant over the register file (spills into the hot loop).
+  f32x4 set[4];
   constexpr int R0 = 4, D0 = R0 - 1;   // weight ring: K step ks in slot ks % 4; a slab holds 4 steps
   static_assert(XS_STEPS == R0, "slab steps == ring slots");
   bf16x8 wr[R0][NB];
@@ -286,9 +287,11 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const Args& a, int64_t ro
   for (int d = 0; d < D0; ++d)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) wr[d][nb] = w[(d * NB + nb) * 64];
-  lwrite(0, setA, true);
-  lwrite(SLAB_BYTES, setB, true);
-  gload(2, setA);
+  gload(0, set);
+  lwrite(0, set, true);
+  gload(1, set);
+  lwrite(SLAB_BYTES, set, true);
+  gload(2, set);
   __syncthreads();
 
   const int lane_off = (c.f * S_XS + 8 * c.h) * 2;   // bytes
@@ -296,10 +299,10 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const Args& a, int64_t ro
 #pragma unroll
   for (int fb = 0; fb < NFB; ++fb) xr[0][fb] = *reinterpret_cast<const bf16x8*>(c.lds + O_XS + lane_off + fb * (32 * S_XS * 2));
 
-  auto slab = [&](int s, int o_cur, int o_next, int o_wr, f32x4 (&ld)[4], f32x4 (&wrset)[4]) {
-    gload(s + 3, ld);
-    const char* xrow = c.lds + O_XS + o_cur + lane_off;
-    const char* xnext = c.lds + O_XS + o_next + lane_off;
+  int o0 = 0, o1 = SLAB_BYTES, o2 = 2 * SLAB_BYTES;   // buffers of slabs s, s+1, s+2
+  for (int s = 0; s < nslab; ++s) {
+    const char* xrow = c.lds + O_XS + o0 + lane_off;
+    const char* xnext = c.lds + O_XS + o1 + lane_off;
 #pragma unroll
     for (int kk = 0; kk < XS_STEPS; ++kk) {
       const bf16x8* wp = w + (size_t)(s * XS_STEPS + kk + D0) * (NB * 64);
@@ -310,7 +313,10 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const Args& a, int64_t ro
         xr[(kk + 1) & 1][fb] = (kk + 1 < XS_STEPS)
                                    ? *reinterpret_cast<const bf16x8*>(xrow + fb * (32 * S_XS * 2) + 32 * (kk + 1))
                                    : *reinterpret_cast<const bf16x8*>(xnext + fb * (32 * S_XS * 2));
-      if (kk == 2) lwrite(o_wr, wrset, s + 2 < nslab);
+      if (kk == 1) {
+        lwrite(o2, set, s + 2 < nslab);
+        gload(s + 3, set);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
@@ -320,13 +326,8 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const Args& a, int64_t ro
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
-  };
-  int o0 = 0, o1 = SLAB_BYTES, o2 = 2 * SLAB_BYTES;
-  for (int s = 0; s < nslab; s += 2) {
-    slab(s, o0, o1, o2, setB, setA);
-    slab(s + 1, o1, o2, o0, setA, setB);
-    const int t0 = o0, t1 = o1;
-    o0 = o2; o1 = t0; o2 = t1;
+    const int t0 = o0;   // rotate: (o0, o1, o2) <- (o1, o2, o0)
+    o0 = o1; o1 = o2; o2 = t0;
   }
   if (a.valid) {  // all-zero feature row == "no face" (FeatureExtractor.py:105-106); 4 lanes share a row
     const unsigned long long m = __ballot(nzbits != 0u);
