@@ -39,7 +39,11 @@ def NLML_HPE_Tester(argv=None):
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("NLML_DIST_BACKEND", "nccl")     # "gloo" only to rehearse the N>1 plumbing
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     bins = load_config("configs/config_EncoderTrainer.yaml")
     cfg = load_config("configs/config_NLML_HPE_Test.yaml")

@@ -268,6 +268,18 @@ def extra_workloads(ops, synth, weights, dev, heads, blob, raw, feats, B):
     ms = time_kernel(lambda: ops.tucker_objective(Wm, feats[:N], P, cp), 20)
     ex["k3_tucker_objective"] = {"evals_per_sec": N / ms * 1e3, "tflops_f64": N * TUCKER_FLOP_PER_EVAL / ms / 1e9,
                                  "f64_frac": N * TUCKER_FLOP_PER_EVAL / ms / 1e9 / PEAK_F64_TFLOPS, "n": N}
+    # host-resident batch: pinned staging + copy stream overlapped with compute (PCIe-inclusive; never `value`)
+    from nlml_hpe_amd.model import HIPPoseModel
+    from nlml_hpe_amd.pipeline import HostPipeline
+    mdl = HIPPoseModel(sd1404, heads, device=dev)
+    pipe = HostPipeline(mdl, batch=16384)
+    raw_host = raw.cpu().numpy()
+    pipe.run(raw_host[:32768])
+    t0 = time.perf_counter()
+    pipe.run(raw_host)
+    dt = time.perf_counter() - t0
+    ex["host_resident_pcie_inclusive"] = {"faces_per_sec": B / dt, "gb_per_s_h2d": B * 5616 / dt / 1e9,
+                                          "note": "host numpy -> pinned -> H2D (copy stream) -> fused kernel -> D2H, double-buffered"}
     # TD end-to-end (TD_Tester.Test): device-side lock-step Powell, one minimisation per face
     from oracle import tucker as TK    # test-infra helper only used to synthesise grid faces (inputs), not measured
     idx = synth.tucker_grid_indices(4096, seed=2)     # BASELINE.json config 3: 4,096 faces

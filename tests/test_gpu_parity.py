@@ -453,3 +453,19 @@ def test_bf16_fused_landmarks(head_sds, device):
     assert not bool(valid[11]) and int(valid.sum()) == 199
     ref = EH.forward_numpy(FN.normalize_ipd(raw, True), EH.Params(sd, head_sds), np.float64)
     assert np.degrees(np.abs(fused.cpu().numpy() - ref).max()) <= 0.5
+
+
+def test_host_pipeline_overlapped_copies(head_sds, device):
+    """Host-resident landmarks through the double-buffered copy/compute pipeline == the direct device call."""
+    from nlml_hpe_amd.model import HIPPoseModel
+    from nlml_hpe_amd.pipeline import HostPipeline
+    model = HIPPoseModel(synth.encoder_state_dict(1404, seed=0), head_sds, device=device)
+    raw = synth.raw_landmarks(5000, seed=77)
+    raw[123] = 0.0
+    pipe = HostPipeline(model, batch=1024)
+    pose, valid = pipe.run(raw)
+    ref, vref = model.from_landmarks(torch.from_numpy(raw).to(device), True, return_valid=True)
+    assert np.array_equal(pose, ref.cpu().numpy()) and np.array_equal(valid, vref.cpu().numpy())
+    assert not valid[123]
+    pose2, _ = pipe.run(raw[:10])           # reuse with a short tail
+    assert np.array_equal(pose2, pose[:10])
