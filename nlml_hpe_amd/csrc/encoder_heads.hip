@@ -24,10 +24,15 @@
 //     interleaved in two passes: pass A computes neurons 0..511 of layer 0 into LDS and layer 1
 //     accumulates over that K half; pass B does neurons 512..1023 in place and layer 1 finishes.
 //     Layer 1's 128 accumulator registers per lane stay live across pass B;
-//   * layer 0 streams x through a double-buffered 64x32 LDS slab (coalesced 128-B row segments),
-//     optionally applying the IPD normalisation (FeatureExtractor.py:30-66) in f64 on the way
-//     in, so normalised features never exist in HBM;
-//   * E4, E5 and the heads (10 % of the FLOPs) run per 32-face block with the 32-face LDS images.
+//   * layer 0 streams x through three rotating 64x32 LDS slabs (coalesced 128-B row segments; global
+//     loads 3 slabs ahead, LDS write under the previous slab's MFMAs, first operands of the next slab
+//     read before the barrier), optionally applying the IPD normalisation (FeatureExtractor.py:30-66)
+//     in f64 on the way in, one element per MFMA gap, so normalised features never exist in HBM;
+//   * E4, E5 and the heads (10 % of the FLOPs) run per 32-face block with the 32-face LDS images; the
+//     jobs a wave owns in a head stage run in lock step through one weight ring (kloop_grouped);
+//   * the hot loops contain no runtime branch, no exec-masked load and no use of a loaded value ahead of
+//     the MFMAs it is prefetched for: any of these makes hipcc 7.2 emit s_waitcnt vmcnt(0) and drain the
+//     prefetch ring every step ("What it took").
 #include <hip/hip_runtime.h>
 
 #include "../../include/nlml_hpe.h"
