@@ -280,6 +280,29 @@ def extra_workloads(ops, synth, weights, dev, heads, blob, raw, feats, B):
     dt = time.perf_counter() - t0
     ex["host_resident_pcie_inclusive"] = {"faces_per_sec": B / dt, "gb_per_s_h2d": B * 5616 / dt / 1e9,
                                           "note": "host numpy -> pinned -> H2D (copy stream) -> fused kernel -> D2H, double-buffered"}
+    # BASELINE config 5 (per GPU): 64 concurrent streams, one tick = 64 raw-landmark sets -> smoothed pose + axes
+    from nlml_hpe_amd.video import GraphedTick, VideoPoseTracker
+    S, T = 64, 300
+    clips = raw[:S * 8].reshape(8, S, 468, 3)
+    for label in ("eager", "hipgraph"):
+        tr = VideoPoseTracker(mdl, S, 1920, 1080)
+        gt = GraphedTick(tr) if label == "hipgraph" else None
+        lat = []
+        for t in range(T + 20):
+            frame = clips[t % 8]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if gt is None:
+                tr.tick(frame)
+            else:
+                gt.static_raw.copy_(frame)
+                gt.replay()
+            torch.cuda.synchronize()
+            if t >= 20:
+                lat.append(time.perf_counter() - t0)
+        lat = np.array(lat)
+        ex[f"video_64_streams_{label}"] = {"tick_ms_p50": float(np.percentile(lat, 50) * 1e3), "tick_ms_p99": float(np.percentile(lat, 99) * 1e3),
+                                           "faces_per_sec_sustained": S / float(lat.mean()), "offered_load_faces_per_sec": 64 * 30}
     # TD end-to-end (TD_Tester.Test): device-side lock-step Powell, one minimisation per face
     from oracle import tucker as TK    # test-infra helper only used to synthesise grid faces (inputs), not measured
     idx = synth.tucker_grid_indices(4096, seed=2)     # BASELINE.json config 3: 4,096 faces

@@ -50,3 +50,33 @@ class VideoPoseTracker:
         pose, valid = self.model.from_landmarks(raw, normalize=True, return_valid=True)
         sm, c, ep = self.post(pose, raw, valid)
         return sm, c, ep, valid
+
+
+class GraphedTick:
+    """One tick (fused forward + post-processing, 2 launches) captured into a hipGraph and replayed.
+
+    The launch functions allocate nothing and never synchronise (include/nlml_hpe.h), so a launch-bound
+    loop -- 64 faces per tick is one tile on one CU; the cost is launch latency -- replays as one graph.
+    Usage: g = GraphedTick(tracker); g.static_raw.copy_(raw_t); sm, centre, ep, valid = g.replay()
+    """
+
+    def __init__(self, tracker: VideoPoseTracker):
+        self.tracker = tracker
+        dev = tracker.model.device
+        self.static_raw = torch.zeros((tracker.S, 468, 3), dtype=torch.float32, device=dev)
+        saved = tracker.state.clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                  # warm-up outside capture
+            for _ in range(2):
+                tracker.tick(self.static_raw)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        tracker.state.copy_(saved)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = tracker.tick(self.static_raw)
+        tracker.state.copy_(saved)                     # the capture itself does not execute the tick
+
+    def replay(self):
+        self.graph.replay()
+        return self.outputs

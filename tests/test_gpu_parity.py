@@ -469,3 +469,21 @@ def test_host_pipeline_overlapped_copies(head_sds, device):
     assert not valid[123]
     pose2, _ = pipe.run(raw[:10])           # reuse with a short tail
     assert np.array_equal(pose2, pose[:10])
+
+
+def test_graphed_video_tick_matches_eager(head_sds, device):
+    from nlml_hpe_amd.model import HIPPoseModel
+    from nlml_hpe_amd.video import GraphedTick, VideoPoseTracker
+    model = HIPPoseModel(synth.encoder_state_dict(1404, seed=0), head_sds, device=device)
+    S = 64
+    frames = torch.from_numpy(synth.raw_landmarks(S * 5, seed=8).reshape(5, S, 468, 3) * 0.2 + 0.4).to(device)
+    frames[2, 7] = 0.0                                   # a stream without a face in one tick
+    a, b = VideoPoseTracker(model, S, 1920, 1080), VideoPoseTracker(model, S, 1920, 1080)
+    g = GraphedTick(b)
+    for t in range(5):
+        sm_a, c_a, ep_a, v_a = a.tick(frames[t])
+        g.static_raw.copy_(frames[t])
+        sm_b, c_b, ep_b, v_b = g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(sm_a, sm_b) and torch.equal(c_a, c_b) and torch.equal(ep_a, ep_b) and torch.equal(v_a, v_b)
+    assert torch.equal(a.state, b.state)

@@ -70,3 +70,25 @@ def test_state_machine_on_the_tucker_objective(golden_dir, tucker_art):
     got = minimize_powell(lambda p: TK.objective(p, W, x, Py, Pp, Pr), np.zeros(8))
     assert got.nfev == g["nfev"][i]
     assert np.allclose(np.degrees(got.x[:3]), g["deg"][i], rtol=0, atol=1e-9)
+
+
+def test_state_machine_follows_scipy_on_random_functions():
+    """Property test: random positive-definite quadratics plus a random smooth non-convex term, random starts."""
+    from nlml_hpe_amd import synth
+    g = synth.rng(99, 0)
+    for trial in range(12):
+        A = g.standard_normal((8, 8))
+        Q = A @ A.T + 0.5 * np.eye(8)
+        c = g.standard_normal(8)
+        amp = 0.3 * g.random()
+        freq = 1.0 + 3.0 * g.random(8)
+
+        def fun(x, Q=Q, c=c, amp=amp, freq=freq):
+            return float(0.5 * x @ Q @ x - c @ x + amp * np.sum(np.cos(freq * x)))
+        x0 = g.standard_normal(8) if trial % 2 else np.zeros(8)
+        ref, ref_pts = _scipy(fun, x0)
+        pts = []
+        got = minimize_powell(fun, x0, record=pts)
+        assert got.nfev == ref.nfev and got.nit == ref.nit, trial
+        assert all(np.array_equal(a, b) for a, b in zip(pts, ref_pts)), trial
+        assert np.array_equal(got.x, ref.x) and got.fun == ref.fun, trial
