@@ -391,7 +391,7 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
     g.r0a = g.r0c; g.r0b = a0; g.r0c = b0;
     g.r1a = g.r1c; g.r1b = a1; g.r1c = b1;
   };
-  auto lw_finish = [&](int buf_off, f32x4 (&st)[2], bool real_slab) {
+  auto lw_nz = [&](f32x4 (&st)[2], bool real_slab) {
     // (the clamped extra slabs staged at the end of a pass are never read and do not count)
     const unsigned m = real_slab ? 0x7fffffffu : 0u;
 #pragma unroll
@@ -399,9 +399,15 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
       g.nzbits0 |= __float_as_uint(st[0][e]) & m;
       g.nzbits1 |= __float_as_uint(st[1][e]) & m;
     }
-    float* d = xs + buf_off;
-    *reinterpret_cast<f32x4*>(d + g.srow * S_XS + g.scol) = st[0];
-    *reinterpret_cast<f32x4*>(d + (g.srow + 32) * S_XS + g.scol) = st[1];
+  };
+  auto lw_store = [&](int buf_off, f32x4 (&st)[2]) {
+    float* d = xs + buf_off + g.srow * S_XS + g.scol;
+    *reinterpret_cast<f32x4*>(d) = st[0];
+    *reinterpret_cast<f32x4*>(d + 32 * S_XS) = st[1];
+  };
+  auto lw_finish = [&](int buf_off, f32x4 (&st)[2], bool real_slab) {
+    lw_nz(st, real_slab);
+    lw_store(buf_off, st);
   };
   auto lwrite = [&](int s, int buf_off, f32x4 (&st)[2]) {   // un-pipelined form (prologue only)
     lw_begin(st);
@@ -457,9 +463,6 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
   // slab s+2.  o_cur / o_next / o_wr: LDS offsets of the buffers of slabs s, s+1, s+2 (rotated by the caller,
   // so no modulo-3 arithmetic sits between the MFMAs).
   auto slab = [&](int s, int o_cur, int o_next, int o_wr, f32x4 (&ld)[2], f32x4 (&wrset)[2]) {
-#ifndef EXP_NO_STAGE
-    gload(s + 3, ld);
-#endif
     const float* xrow = xs + o_cur + lane_off;
     const float* xnext = xs + o_next + lane_off;
 #pragma unroll
@@ -477,11 +480,13 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
 #ifdef EXP_NO_STAGE
             return;
 #endif
+            if (kk == 0 && j == 2) gload(s + 3, ld);          // its own gap: address arithmetic + 2 loads
             if (kk == 1 && j == 0) lw_begin(wrset);
             if (NORM && kk == 1) lw_norm(wrset, 0, j);
             if (NORM && kk == 2) lw_norm(wrset, 1, j);
             if (NORM && kk == 3 && j == 0) lw_rotate();
-            if (kk == 3 && j == 0) lw_finish(o_wr, wrset, s + 2 < nslab);
+            if (kk == 3 && j == 1) lw_nz(wrset, s + 2 < nslab);
+            if (kk == 3 && j == 2) lw_store(o_wr, wrset);
           });
     }
 #ifndef EXP_NO_BAR
