@@ -313,13 +313,13 @@ struct E0Stager {
   unsigned nzbits0, nzbits1;   // OR of the magnitude bits of every staged value of the row
 };
 
-template <bool NORM>
+template <bool NORM, int NFB>
 __device__ __forceinline__ void e0_stager_init(E0Stager& g, const EncArgs& a, int64_t row0, int tid) {
   g.srow = tid >> 3;
   g.scol = (tid & 7) * 4;
   int64_t r0 = row0 + g.srow, r1 = row0 + g.srow + 32;
   g.live0 = r0 < a.B;
-  g.live1 = r1 < a.B;
+  g.live1 = NFB == 2 && r1 < a.B;   // a 32-face tile has no second row set
   r0 = g.live0 ? r0 : a.B - 1;
   r1 = g.live1 ? r1 : a.B - 1;
   g.p0 = a.x + r0 * a.ldx;
@@ -330,14 +330,14 @@ __device__ __forceinline__ void e0_stager_init(E0Stager& g, const EncArgs& a, in
   g.r0a = g.r0b = g.r0c = g.r1a = g.r1b = g.r1c = 0.0;
   if (NORM) {  // IPD normalisation constants of the two rows (FeatureExtractor.py:38-48,85-86), f64
     ipd_of_row(g.p0, g.ipd0, g.rcp0);
-    ipd_of_row(g.p1, g.ipd1, g.rcp1);
+    if (NFB == 2) ipd_of_row(g.p1, g.ipd1, g.rcp1);
   }
 }
 
-template <bool VEC4, bool NORM>
+template <bool VEC4, bool NORM, int NFB>
 __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0Stager& g, int job,
-                                              f32x16 (&acc)[4][2]) {
-  constexpr int NB = 4, NFB = 2;
+                                              f32x16 (&acc)[4][NFB]) {
+  constexpr int NB = 4;
   float* xs = c.lds + O_XS;
   const int F = a.F;
   const int nslab = (int)c.hdr->k8_e0 / XS_STEPS;   // even: k8_e0 is a multiple of 2*XS_STEPS (pack.cpp)
@@ -359,13 +359,13 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
       // the (x, y, z) phase -- hence the normalised value, hence the all-zero test -- matches column k
       const int kc = k < F ? k : (NORM ? k - 12 * ((k - F + 15) / 12) : F - 4);
       st[0] = *reinterpret_cast<const f32x4*>(g.p0 + kc);
-      st[1] = *reinterpret_cast<const f32x4*>(g.p1 + kc);
+      if (NFB == 2) st[1] = *reinterpret_cast<const f32x4*>(g.p1 + kc);
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int kc = k + e < F ? k + e : F - 1;
         st[0][e] = g.p0[kc];
-        st[1][e] = g.p1[kc];
+        if (NFB == 2) st[1][e] = g.p1[kc];
       }
     }
   };
@@ -376,7 +376,8 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
   // The staging of one slab is cut into pieces that each fit the shadow of one MFMA (64 cycles) and are
   // dropped into consecutive gaps of the K steps: 8 x normalise-one-element (NORM only), then the write.
   auto lw_begin = [&](f32x4 (&st)[2]) {
-    asm volatile("" : "+v"(st[0]), "+v"(st[1]));   // consumers of the loaded values stay where written
+    asm volatile("" : "+v"(st[0]));   // consumers of the loaded values stay where written
+    if (NFB == 2) asm volatile("" : "+v"(st[1]));
   };
   // r0a..r1c: the rows' reference coordinates in the order this thread's 4 columns of the CURRENT write
   // slab need them (element e uses slot e % 3); lw_rotate() steps them to the next slab (a slab is 32
@@ -397,13 +398,13 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       g.nzbits0 |= __float_as_uint(st[0][e]) & m;
-      g.nzbits1 |= __float_as_uint(st[1][e]) & m;
+      if (NFB == 2) g.nzbits1 |= __float_as_uint(st[1][e]) & m;
     }
   };
   auto lw_store = [&](int buf_off, f32x4 (&st)[2]) {
     float* d = xs + buf_off + g.srow * S_XS + g.scol;
     *reinterpret_cast<f32x4*>(d) = st[0];
-    *reinterpret_cast<f32x4*>(d + 32 * S_XS) = st[1];
+    if (NFB == 2) *reinterpret_cast<f32x4*>(d + 32 * S_XS) = st[1];
   };
   auto lw_finish = [&](int buf_off, f32x4 (&st)[2], bool real_slab) {
     lw_nz(st, real_slab);
@@ -413,7 +414,7 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
     lw_begin(st);
     if (NORM) {
 #pragma unroll
-      for (int row = 0; row < 2; ++row)
+      for (int row = 0; row < NFB; ++row)
 #pragma unroll
         for (int e = 0; e < 4; ++e) lw_norm(st, row, e);
       lw_rotate();
@@ -427,7 +428,7 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
   if (NORM) {  // phase of slab 0: this thread's first column is scol, element e is column scol + e;
                // landmark 1 (columns 3,4,5) is the reference point (FeatureExtractor.py:85-86)
     const double x0 = (double)g.p0[3], y0 = (double)g.p0[4], z0 = (double)g.p0[5];
-    const double x1 = (double)g.p1[3], y1 = (double)g.p1[4], z1 = (double)g.p1[5];
+    const double x1 = NFB == 2 ? (double)g.p1[3] : 0.0, y1 = NFB == 2 ? (double)g.p1[4] : 0.0, z1 = NFB == 2 ? (double)g.p1[5] : 0.0;
     const int ph = g.scol % 3;   // coordinate (0 x, 1 y, 2 z) of this thread's first column
     g.r0a = ph == 0 ? x0 : (ph == 1 ? y0 : z0);
     g.r0b = ph == 0 ? y0 : (ph == 1 ? z0 : x0);
@@ -483,7 +484,7 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
             if (kk == 0 && j == 2) gload(s + 3, ld);          // its own gap: address arithmetic + 2 loads
             if (kk == 1 && j == 0) lw_begin(wrset);
             if (NORM && kk == 1) lw_norm(wrset, 0, j);
-            if (NORM && kk == 2) lw_norm(wrset, 1, j);
+            if (NORM && NFB == 2 && kk == 2) lw_norm(wrset, 1, j);
             if (NORM && kk == 3 && j == 0) lw_rotate();
             if (kk == 3 && j == 1) lw_nz(wrset, s + 2 < nslab);
             if (kk == 3 && j == 2) lw_store(o_wr, wrset);
@@ -513,7 +514,9 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const EncArgs& a, E0
       a.stamps[((size_t)blockIdx.x * 4 + wv) * 16 + (i)] = __builtin_amdgcn_s_memtime();         \
   } while (0)
 
-template <bool VEC4, bool NORM, bool DBG>
+// NFB = face blocks per tile: 2 (64 faces, every weight fragment feeds 8 MFMAs) for large batches, 1 (32 faces)
+// for batches too small to give every CU a 64-face tile.
+template <bool VEC4, bool NORM, bool DBG, int NFB>
 __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
@@ -527,28 +530,29 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
   c.h = c.lane >> 5;
   c.wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wv = c.wv;
-  const int64_t row0 = (int64_t)blockIdx.x * TILE_FACES;
+  constexpr int TILE = 32 * NFB;
+  const int64_t row0 = (int64_t)blockIdx.x * TILE;
 
   {  // ---- layers 0 and 1 interleaved in two passes over x (see header)
     E0Stager g;
-    e0_stager_init<NORM>(g, a, row0, tid);
-    f32x16 acc1[4][2];  // layer 1: neurons 128*wv .. +127, both face blocks; live across pass B
-    load_bias<4, 2>(acc1, c.blob4 + c.hdr->b_off[ST_E1] + wv * (4 * 8), c.h);
+    e0_stager_init<NORM, NFB>(g, a, row0, tid);
+    f32x16 acc1[4][NFB];  // layer 1: neurons 128*wv .. +127, all face blocks; live across pass B
+    load_bias<4, NFB>(acc1, c.blob4 + c.hdr->b_off[ST_E1] + wv * (4 * 8), c.h);
     const f32x4* w1 = c.blob4 + c.hdr->w_off[ST_E1] + (size_t)wv * c.hdr->job_w16[ST_E1] + c.lane;
     NLML_STAMP(0);
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       {  // E0 half: F -> neurons 512*pass + 128*wv .. +127, ReLU
-        f32x16 acc0[4][2];
-        stage_e0_pass<VEC4, NORM>(c, a, g, pass * 4 + wv, acc0);
+        f32x16 acc0[4][NFB];
+        stage_e0_pass<VEC4, NORM, NFB>(c, a, g, pass * 4 + wv, acc0);
         NLML_STAMP(1 + 4 * pass);
         // the previous pass's h1 half was fully consumed before this pass's slab barriers
-        job_store<4, 2, ACT_RELU>(c, acc0, lds + O_H1H, S_H1H, 128 * wv, 0);
+        job_store<4, NFB, ACT_RELU>(c, acc0, lds + O_H1H, S_H1H, 128 * wv, 0);
       }
       __syncthreads();
       NLML_STAMP(2 + 4 * pass);
       // E1 over this K half: k = 512*pass .. +511  (64 steps of 8)
-      kloop_lds<4, 2, 64>(acc1, w1 + (size_t)pass * 64 * (4 * 64), lds + O_H1H + c.f * S_H1H + 4 * c.h, 32 * S_H1H);
+      kloop_lds<4, NFB, 64>(acc1, w1 + (size_t)pass * 64 * (4 * 64), lds + O_H1H + c.f * S_H1H + 4 * c.h, 32 * S_H1H);
       NLML_STAMP(3 + 4 * pass);
       __syncthreads();  // all waves done reading this h1 half before it is overwritten
       NLML_STAMP(4 + 4 * pass);
@@ -561,26 +565,26 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
         if (g.live1) a.valid[row0 + g.srow + 32] = ((m1 >> sh) & 0xFFull) ? 1 : 0;
       }
     }
-    job_store<4, 2, ACT_RELU>(c, acc1, lds + O_H2, S_H2, 128 * wv, 0);
+    job_store<4, NFB, ACT_RELU>(c, acc1, lds + O_H2, S_H2, 128 * wv, 0);
   }
   __syncthreads();
   NLML_STAMP(9);
   {  // E2: 512 -> 256, ReLU.  h3 overwrites h2 => barrier between the K loop and the store
-    f32x16 acc[2][2];
-    job_compute<2, 2, ST_E2>(c, wv, acc, lds + O_H2, S_H2, 0, 0);
+    f32x16 acc[2][NFB];
+    job_compute<2, NFB, ST_E2>(c, wv, acc, lds + O_H2, S_H2, 0, 0);
     __syncthreads();
-    job_store<2, 2, ACT_RELU>(c, acc, lds + O_H3, S_H3, 64 * wv, 0);
+    job_store<2, NFB, ACT_RELU>(c, acc, lds + O_H3, S_H3, 64 * wv, 0);
   }
   __syncthreads();
   NLML_STAMP(10);
   {  // E3: 256 -> 128, ReLU
-    f32x16 acc[1][2];
-    job_compute<1, 2, ST_E3>(c, wv, acc, lds + O_H3, S_H3, 0, 0);
-    job_store<1, 2, ACT_RELU>(c, acc, lds + O_H4, S_H4, 32 * wv, 0);
+    f32x16 acc[1][NFB];
+    job_compute<1, NFB, ST_E3>(c, wv, acc, lds + O_H3, S_H3, 0, 0);
+    job_store<1, NFB, ACT_RELU>(c, acc, lds + O_H4, S_H4, 32 * wv, 0);
   }
   __syncthreads();
   NLML_STAMP(11);
-  {  // E4: 128 -> 64, Tanh.  4 single-face-block jobs: neuron block wv&1, face block wv>>1
+  if (wv < 2 * NFB) {  // E4: 128 -> 64, Tanh.  Single-face-block jobs: neuron block wv&1, face block wv>>1
     const int nb = wv & 1, face0 = 32 * (wv >> 1);
     f32x16 acc[1][1];
     job_compute<1, 1, ST_E4>(c, nb, acc, lds + O_H4, S_H4, 0, face0);
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
     job_store<1, 1, ACT_TANH>(c, acc, lds + O_H5, S_H5, 32 * nb, face0);
   }
   __syncthreads();
-  if (wv < 2) {  // E5: 64 -> 9 (latent n = 3g+c on row 8g+c, other rows exact zeros); face block wv
+  if (wv < NFB) {  // E5: 64 -> 9 (latent n = 3g+c on row 8g+c, other rows exact zeros); face block wv
     f32x16 acc[1][1];
     job_compute<1, 1, ST_E5>(c, 0, acc, lds + O_H5, S_H5, 0, 32 * wv);
     job_store<1, 1, ACT_NONE>(c, acc, lds + O_LAT, S_LAT, 0, 32 * wv);
@@ -600,7 +604,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
   __syncthreads();
   NLML_STAMP(12);
   if (a.latent) {  // optional: the encoder output before the split (Model_Builder.py:58)
-    for (int i = tid; i < TILE_FACES * NLML_LATENT; i += 256) {
+    for (int i = tid; i < TILE * NLML_LATENT; i += 256) {
       const int ff = i / NLML_LATENT, n = i % NLML_LATENT;
       if (row0 + ff < a.B) a.latent[(row0 + ff) * NLML_LATENT + n] = lds[O_LAT + ff * S_LAT + 8 * (n / 3) + (n % 3)];
     }
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
   // ---- heads (yaw, pitch, roll = g 0,1,2), one 32-face block at a time.  A stage's jobs are (head,
   // neuron block) pairs; the jobs a wave owns run together through kloop_grouped.
 #pragma unroll 1
-  for (int fb = 0; fb < 2; ++fb) {
+  for (int fb = 0; fb < NFB; ++fb) {
     const int face0 = 32 * fb;
     const int lrow = c.f;   // row of the 32-face head images
     {  // H0: 3 -> 128 (K padded to 8 with zeros), ReLU.  12 jobs (g, nb), 3 per wave
@@ -719,18 +723,28 @@ int launch_encoder_heads_f32(const float* x, int64_t ldx, const float* raw, int 
     a.ldx = ldx;
   }
   const bool vec4 = (F % 4 == 0) && (a.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
-  const dim3 grid((unsigned)((B + TILE_FACES - 1) / TILE_FACES)), block(256);
+  // 64-face tiles halve the weight stream per face (a 64-face tile takes ~1.9x a 32-face tile, measured), but the
+  // launch lasts whole ROUNDS of tiles over the 256 CUs (one tile per CU, LDS-bound): pick the tiling whose
+  // rounds x tile time is smaller, so small batches and awkward tile counts (257 tiles = 2 rounds) do not pay for it.
+  const int64_t rounds64 = ((B + 63) / 64 + 255) / 256, rounds32 = ((B + 31) / 32 + 255) / 256;
+  const bool wide = rounds64 * 19 <= rounds32 * 10;
+  const int tile = wide ? 64 : 32;
+  const dim3 grid((unsigned)((B + tile - 1) / tile)), block(256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define NLML_LAUNCH(V, N, D)                                                                          \
+  do {                                                                                                \
+    if (wide) hipLaunchKernelGGL((encoder_heads_f32_kernel<V, N, D, 2>), grid, block, 0, st, a);      \
+    else hipLaunchKernelGGL((encoder_heads_f32_kernel<V, N, D, 1>), grid, block, 0, st, a);           \
+  } while (0)
   if (dbg) {
     if (a.norm || !vec4) return fail(NLML_E_BADARG, "debug build: features input, F % 4 == 0 only");
-    hipLaunchKernelGGL((encoder_heads_f32_kernel<true, false, true>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((encoder_heads_f32_kernel<true, false, true, 2>), dim3((unsigned)((B + 63) / 64)), block, 0, st, a);
   } else if (a.norm) {
-    if (vec4) hipLaunchKernelGGL((encoder_heads_f32_kernel<true, true, false>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((encoder_heads_f32_kernel<false, true, false>), grid, block, 0, st, a);
+    if (vec4) NLML_LAUNCH(true, true, false); else NLML_LAUNCH(false, true, false);
   } else {
-    if (vec4) hipLaunchKernelGGL((encoder_heads_f32_kernel<true, false, false>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((encoder_heads_f32_kernel<false, false, false>), grid, block, 0, st, a);
+    if (vec4) NLML_LAUNCH(true, false, false); else NLML_LAUNCH(false, false, false);
   }
+#undef NLML_LAUNCH
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
 }

@@ -60,3 +60,17 @@ for F, B in ((1404, 65536), (136, 65536)):
     ms = e0.elapsed_time(e1) / 10
     flops = {1404: 4714240, 136: 2117376}[F]
     print(f"K2-bf16 F={F} B={B}: {ms:.3f} ms  {B/ms*1e3/1e6:.2f} Mfaces/s  {B*flops/ms/1e9:.1f} TFLOP/s ({B*flops/ms/1e9/2500*100:.1f}% of bf16 MFMA peak)")
+F = 1404
+blob = torch.from_numpy(weights.pack_blob(synth.encoder_state_dict(F, 0), heads)).to(dev)
+for B in (64, 2000, 8192, 16384, 16448, 32768):
+    x = torch.from_numpy(synth.features(B, F, 1)).to(dev)
+    for _ in range(3):
+        ops.encoder_heads_fwd(x, blob, F)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.encoder_heads_fwd(x, blob, F)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    print(f"K2 small-batch F={F} B={B}: {ms:.3f} ms  {B/ms*1e3/1e6:.2f} Mfaces/s")
