@@ -307,7 +307,20 @@ def test_entry_points_run(repo_root, device, tmp_path, capsys):
         res = subprocess.run([sys.executable] + cmd, cwd=repo_root, env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, (cmd, res.stdout[-2000:], res.stderr[-2000:])
         if cmd[0] == "NLML_HPE_Test.py":
-            assert "MAE (Yaw)" in res.stdout and "MAEV" in res.stdout
+            # BASELINE config 1 shape (256 rows): the printed metrics block must equal what the oracle computes from
+            # the same synthetic landmarks, weights and ground truth (reference: NLML_HPE_Test.py:95-130, :273)
+            from oracle import metrics as MT
+            raw = synth.raw_landmarks(256, seed=1)
+            gt = synth.poses_deg(256, seed=4)
+            P = EH.Params(synth.encoder_state_dict(1404, seed=0), weights.load_head_state_dicts(os.path.join(repo_root, "models")))
+            pred = np.round(np.degrees(EH.forward_numpy(FN.normalize_ipd(raw, True), P, np.float32).astype(np.float64)), 3)
+            lo, hi = np.array([-50, -40, -30.0]), np.array([51, 41, 31.0])
+            keep = ((gt >= lo) & (gt <= hi)).all(axis=1)
+            exp = MT.compute_errors(gt[keep], pred[keep])
+            printed = dict(line.split(": ", 1) for line in res.stdout.splitlines() if ": " in line)
+            for key, label in (("mae_yaw", "MAE (Yaw)"), ("mae_pitch", "MAE (Pitch)"), ("mae_roll", "MAE (Roll)"),
+                               ("mae_total", "Total MAE"), ("maev", "MAEV"), ("std_yaw", "std (Yaw)")):
+                assert printed[label] == f"{exp[key]:.2f}", (label, printed[label], exp[key])
         if cmd[0] == "TD_Inference.py":
             assert res.stdout.count("Estimated yaw in degree") == 3
     out = np.load(tmp_path / "p.npz")
