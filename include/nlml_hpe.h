@@ -70,11 +70,16 @@ int nlml_normalize_ipd(const float* raw, int64_t B, int normalize,
  * (the state-dict layout of models/Encoder.pth and models/{yaw,pitch,roll}_network.pth).
  * mode: NLML_MODE_F32 = f32 storage + f32 MFMA (parity mode, <=1e-4 deg of the reference);
  *       NLML_MODE_BF16 = bf16 weights and activations + bf16 MFMA, f32 accumulate (throughput mode:
- *       ~5x the faces/s; its error is ~0.1 deg max / 0.02 deg mean and is never claimed as parity).
+ *       ~5x the faces/s; its error is ~0.1 deg max / 0.02 deg mean and is never claimed as parity);
+ *       NLML_MODE_F16X2 = split-f16 parity mode: every f32 weight and activation is carried as two f16
+ *       pieces (hi + lo, 22 significand bits) and a product runs as three f16 MFMAs with f32 accumulation.
+ *       Same <=1e-4 deg bar as NLML_MODE_F32 (measured ~1e-5 deg), ~2x its faces/s; |activation| must stay
+ *       below 65504 (f16 range) -- a face that exceeds it yields NaN, never a silently wrong pose.
  * The forward entry points recognise the mode of a blob by its size.
  */
-#define NLML_MODE_F32  0
-#define NLML_MODE_BF16 1
+#define NLML_MODE_F32   0
+#define NLML_MODE_BF16  1
+#define NLML_MODE_F16X2 2
 
 size_t nlml_encoder_heads_packed_bytes(int F, int mode);
 int    nlml_encoder_heads_pack(int F, int mode,

@@ -42,6 +42,7 @@ SYMBOLS = {
 
 MODE_F32 = 0
 MODE_BF16 = 1
+MODE_F16X2 = 2
 
 _lib = None
 

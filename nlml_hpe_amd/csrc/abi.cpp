@@ -18,6 +18,8 @@ int fail(int code, const char* msg) {
 
 using namespace nlml;
 
+static bool known_mode(int mode) { return mode == NLML_MODE_F32 || mode == NLML_MODE_BF16 || mode == NLML_MODE_F16X2; }
+
 extern "C" {
 
 int nlml_abi_version(void) { return NLML_ABI_VERSION; }
@@ -31,26 +33,28 @@ int nlml_normalize_ipd(const float* raw, int64_t B, int normalize, float* out, u
 }
 
 size_t nlml_encoder_heads_packed_bytes(int F, int mode) {
-  if (F <= 0 || (mode != NLML_MODE_F32 && mode != NLML_MODE_BF16)) return 0;
+  if (F <= 0 || !known_mode(mode)) return 0;
   return blob_bytes_for(F, mode);
 }
 
 int nlml_encoder_heads_pack(int F, int mode, const float* const h_enc_w[6], const float* const h_enc_b[6],
                             const float* const h_head_w[3][5], const float* const h_head_b[3][5], void* h_blob,
                             size_t blob_bytes) {
-  if (mode != NLML_MODE_F32 && mode != NLML_MODE_BF16) return fail(NLML_E_BADARG, "pack: unsupported mode");
+  if (!known_mode(mode)) return fail(NLML_E_BADARG, "pack: unsupported mode");
   if (!h_enc_w || !h_enc_b || !h_head_w || !h_head_b) return fail(NLML_E_BADARG, "pack: null table");
   return pack_blob(F, mode, h_enc_w, h_enc_b, h_head_w, h_head_b, h_blob, blob_bytes);
 }
 
-// The blob lives in device memory; its mode is recognised by its size (the two modes never coincide).
+// The blob lives in device memory; its mode is recognised by its size (the sizes of the modes never coincide:
+// the latent and head-input stages are padded differently in each).
 static int check_blob_args(int64_t B, int F, const void* blob, size_t blob_bytes, const float* out, int* mode) {
   if (B < 0 || F <= 0) return fail(NLML_E_BADARG, "encoder_heads: negative B or bad F");
   if (B > 0 && (!blob || !out)) return fail(NLML_E_BADARG, "encoder_heads: null buffer");
   if (reinterpret_cast<uintptr_t>(blob) & 15) return fail(NLML_E_BADARG, "encoder_heads: blob must be 16-byte aligned");
   if (blob_bytes == blob_bytes_for(F, NLML_MODE_F32)) *mode = NLML_MODE_F32;
   else if (blob_bytes == blob_bytes_for(F, NLML_MODE_BF16)) *mode = NLML_MODE_BF16;
-  else return fail(NLML_E_BADBLOB, "encoder_heads: blob size does not match F in either mode");
+  else if (blob_bytes == blob_bytes_for(F, NLML_MODE_F16X2)) *mode = NLML_MODE_F16X2;
+  else return fail(NLML_E_BADBLOB, "encoder_heads: blob size does not match F in any mode");
   return 0;
 }
 
@@ -60,6 +64,7 @@ int nlml_encoder_heads_fwd(const float* x, int64_t ldx, int64_t B, int F, const 
   if (int rc = check_blob_args(B, F, blob, blob_bytes, out, &mode)) return rc;
   if (B > 0 && (!x || ldx < F)) return fail(NLML_E_BADARG, "encoder_heads: null x or ldx < F");
   if (mode == NLML_MODE_BF16) return launch_encoder_heads_bf16(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, stream);
+  if (mode == NLML_MODE_F16X2) return launch_encoder_heads_f16x2(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, stream);
   return launch_encoder_heads_f32(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, nullptr, nullptr, stream);
 }
 
@@ -79,6 +84,8 @@ int nlml_landmarks_to_pose(const float* raw, int64_t B, int normalize, const voi
   if (B > 0 && !raw) return fail(NLML_E_BADARG, "landmarks_to_pose: null raw");
   if (mode == NLML_MODE_BF16)
     return launch_encoder_heads_bf16(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, stream);
+  if (mode == NLML_MODE_F16X2)
+    return launch_encoder_heads_f16x2(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, stream);
   return launch_encoder_heads_f32(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, nullptr, nullptr, stream);
 }
 

@@ -22,6 +22,10 @@ int launch_encoder_heads_f32(const float* x, int64_t ldx, const float* raw, int 
 int launch_encoder_heads_bf16(const float* x, int64_t ldx, const float* raw, int normalize,
                               int64_t B, int F, const void* blob, float* out, float* latent,
                               uint8_t* valid, void* stream);
+// encoder_heads_f16x2.hip (split-f16 parity mode)
+int launch_encoder_heads_f16x2(const float* x, int64_t ldx, const float* raw, int normalize,
+                               int64_t B, int F, const void* blob, float* out, float* latent,
+                               uint8_t* valid, void* stream);
 // normalize_ipd.hip
 int launch_normalize_ipd(const float* raw, int64_t B, int normalize, float* out, uint8_t* valid,
                          void* stream);

@@ -257,6 +257,9 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const Args& a, int64_t ro
           const double rr = t == 0 ? ra : (t == 1 ? rb : rc);
           st[i][e] = (float)div_ipd((double)st[i][e] - rr, ipd, rcp);
         }
+      // keep the f32 value: otherwise (bf16)(f32)double may be folded into one software f64 -> bf16 conversion
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(st[i]));
       const double t0 = ra; ra = rb; rb = rc; rc = t0;   // next slab: columns + 64 => phase + 1
     }
     const unsigned m = real_slab ? 0x7fffffffu : 0u;

@@ -33,7 +33,7 @@
 namespace nlml {
 
 constexpr uint32_t BLOB_MAGIC = 0x4E4C4D4Cu;  // "NLML"
-constexpr uint32_t BLOB_VERSION = 2;
+constexpr uint32_t BLOB_VERSION = 3;
 
 constexpr int TILE_FACES = 64;   // faces per workgroup tile = 2 MFMA column blocks of 32
 constexpr int NUM_WAVES = 4;
@@ -75,7 +75,8 @@ struct Header {
   uint32_t w_off[NUM_STAGES];  // weights of stage, 16-byte units
   uint32_t b_off[NUM_STAGES];  // bias of stage, 16-byte units
   uint32_t job_w16[NUM_STAGES];  // 16-byte units per job (weights)
-  uint32_t reserved[64 - 6 - 3 * NUM_STAGES];
+  float inv_scale[NUM_STAGES];   // NLML_MODE_F16X2: 2^-e of the stage's power-of-two weight scale (1.0 in the other modes)
+  uint32_t reserved[64 - 6 - 4 * NUM_STAGES];
 };
 static_assert(sizeof(Header) == 256, "header is 256 bytes");
 
@@ -158,5 +159,59 @@ static_assert(O_H5 + 64 * S_H5 * 2 <= O_LAT, "LDS map");
 static_assert(O_HB + 32 * S_HB * 2 <= O_LAT, "LDS map");
 
 }  // namespace bf
+
+// ------------------------------------------------------------------------------------------
+// Split-f16 parity mode (NLML_MODE_F16X2): every f32 operand is carried as TWO f16 pieces, v = hi + lo with
+// hi = f16(v), lo = f16(v - hi) (22 significand bits), and a product w*x is evaluated on the f16 matrix cores as
+// w_hi*x_hi + w_hi*x_lo + w_lo*x_hi (three v_mfma_f32_32x32x16_f16, f32 accumulate; the dropped w_lo*x_lo term is
+// 2^-22 relative).  The weights of a stage are pre-scaled by a power of two (exact) so their lo pieces stay in
+// f16's normal range; the accumulators are scaled back (exactly) before the activation.  Bytes per weight and per
+// activation are the same 4 as in the f32 mode, so the jobs, the two-pass layer 0 and the LDS budget follow the
+// f32 kernel, while a K step is 16 as in the bf16 mode.
+//   weights   wfrag[job][k16 step][nb][piece][lane] : 8 x f16 = 16 bytes per lane, piece 0 = hi, 1 = lo
+//   LDS image [piece][face][k] f16, row stride K+8 elements (odd number of 16-byte chunks)
+namespace hx {
+
+constexpr StageDesc kStages[NUM_STAGES] = {   // k8 field = K steps of 16
+    /*E0  F   ->1024 relu*/ {4, 8, 0, 0},     // jobs 0-3: neurons 0..511 (pass A), 4-7: 512..1023 (pass B)
+    /*E1 1024-> 512 relu*/ {4, 4, 1024, 64},
+    /*E2  512-> 256 relu*/ {2, 4, 512, 32},
+    /*E3  256-> 128 relu*/ {1, 4, 256, 16},
+    /*E4  128->  64 tanh*/ {1, 2, 128, 8},
+    /*E5   64->   9 none*/ {2, 1, 64, 4},     // latent n = 3g+c on row 16g+c
+    /*H0 3x(3->128) relu*/ {1, 12, 3, 1},
+    /*H1 3x(128->256)   */ {2, 12, 128, 8},
+    /*H2 3x(256->128)   */ {1, 12, 256, 16},
+    /*H3 3x(128->64)    */ {1, 6, 128, 8},
+    /*H4 3x(64->1)  none*/ {1, 3, 64, 4},
+};
+constexpr int PIECES = 2;
+constexpr int XS_COLS = 32;             // x slab: 32 columns = 2 K steps of 16
+constexpr int XS_STEPS = XS_COLS / 16;
+// row strides in f16 elements
+constexpr int S_H1H = 520, S_H2 = 520, S_H3 = 264, S_H4 = 136, S_H5 = 72, S_LAT = 56;   // LAT: columns 16g+c, g<3
+constexpr int S_HA = 392, S_HB = 776, S_HC = 392, S_HD = 200, S_XS = 40;
+// plane sizes (bytes) and LDS offsets (bytes); the lo plane of an image follows its hi plane
+constexpr int P_H1H = 64 * S_H1H * 2, P_H2 = 64 * S_H2 * 2, P_H3 = 64 * S_H3 * 2, P_H4 = 64 * S_H4 * 2;
+constexpr int P_H5 = 64 * S_H5 * 2, P_LAT = 64 * S_LAT * 2, P_XS = 64 * S_XS * 2;
+constexpr int P_HA = 32 * S_HA * 2, P_HB = 32 * S_HB * 2, P_HC = 32 * S_HC * 2, P_HD = 32 * S_HD * 2;
+constexpr int LDS_BYTES = 163840;
+constexpr int O_H1H = 0;                                  // 2 x 66560 = 133120; pass A, then pass B in place
+constexpr int O_XS = O_H1H + 2 * P_H1H;                   // 3 slabs x 2 planes x 5120 = 30720 -> ends 163840
+constexpr int O_H2 = 0;                                   // written after layer 1's last K loop (barrier)
+constexpr int O_H3 = 0;                                   // written after layer 2's K loop (barrier): 67584
+constexpr int O_H4 = O_H3 + 2 * P_H3;                     // .. 102400
+constexpr int O_H5 = O_H4 + 2 * P_H4;                     // .. 120832
+constexpr int O_LAT = LDS_BYTES - 2 * P_LAT;              // 149504 .. 163840; survives both head passes
+constexpr int O_HA = 0;                                   // 2 x 25088 = 50176
+constexpr int O_HB = O_HA + 2 * P_HA;                     // .. 149504
+constexpr int O_HC = 0;
+constexpr int O_HD = O_HB;
+static_assert(O_XS + 3 * 2 * P_XS <= LDS_BYTES, "LDS map");
+static_assert(O_H5 + 2 * P_H5 <= O_LAT, "LDS map");
+static_assert(O_HB + 2 * P_HB <= O_LAT, "LDS map");
+static_assert(O_HD + 2 * P_HD <= O_LAT, "LDS map");
+
+}  // namespace hx
 
 }  // namespace nlml

@@ -1,6 +1,7 @@
 // pack.cpp -- host-side packer: reference state-dict weights -> MFMA fragment-order blob.
 // Layout contract: layout.h.  Weight sources follow NLML_HPE_Model_Builder.py:33-53 (encoder)
 // and :76-92 (heads); [out,in] row-major as torch.nn.Linear stores them.
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -46,8 +47,47 @@ static int e0_k8(int F) { return (F + 2 * XS_COLS - 1) / (2 * XS_COLS) * (2 * XS
 // bf16 mode: K steps of 16, x slabs of 64 columns, slab pairs => K padded to 128 columns
 static int e0_k16(int F) { return (F + 2 * bf::XS_COLS - 1) / (2 * bf::XS_COLS) * (2 * bf::XS_STEPS); }
 
-static const StageDesc& stage_of(int mode, int s) { return mode == NLML_MODE_BF16 ? bf::kStages[s] : kStages[s]; }
-static int e0_steps(int mode, int F) { return mode == NLML_MODE_BF16 ? e0_k16(F) : e0_k8(F); }
+// split-f16 mode: K steps of 16, x slabs of 32 columns, slab pairs => K padded to 64 columns
+static int e0_k16x2(int F) { return (F + 2 * hx::XS_COLS - 1) / (2 * hx::XS_COLS) * (2 * hx::XS_STEPS); }
+
+static const StageDesc& stage_of(int mode, int s) {
+  return mode == NLML_MODE_BF16 ? bf::kStages[s] : (mode == NLML_MODE_F16X2 ? hx::kStages[s] : kStages[s]);
+}
+static int e0_steps(int mode, int F) {
+  return mode == NLML_MODE_BF16 ? e0_k16(F) : (mode == NLML_MODE_F16X2 ? e0_k16x2(F) : e0_k8(F));
+}
+static int pieces_of(int mode) { return mode == NLML_MODE_F16X2 ? hx::PIECES : 1; }
+
+
+// round-to-nearest-even f32 -> f16 bits and back (host side of the split; subnormals kept, overflow -> inf)
+static uint16_t to_f16(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  u &= 0x7fffffffu;
+  if (u > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);           // NaN
+  if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);          // >= 65520 rounds to inf
+  if (u < 0x33000001u) return (uint16_t)sign;                       // <= 2^-25 rounds to zero
+  int e = (int)(u >> 23) - 127;
+  uint32_t m = (u & 0x7fffffu) | 0x800000u;                         // 24-bit significand
+  int shift = e < -14 ? 13 + (-14 - e) : 13;                        // bits dropped (subnormal: more)
+  uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (q & 1u))) ++q;
+  uint32_t out = e < -14 ? q : (((uint32_t)(e + 15) << 10) + (q - 0x400u));   // carry ripples into the exponent
+  return (uint16_t)(sign | out);
+}
+static float from_f16(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  float v;
+  if (e == 0) v = (float)m * 5.9604644775390625e-08f;               // 2^-24
+  else if (e == 31) { uint32_t u = 0x7f800000u | (m << 13); std::memcpy(&v, &u, 4); }
+  else { uint32_t u = ((e + 112u) << 23) | (m << 13); std::memcpy(&v, &u, 4); }
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  u |= sign;
+  std::memcpy(&v, &u, 4);
+  return v;
+}
 
 // round-to-nearest-even f32 -> bf16 (NaN stays NaN)
 static uint16_t to_bf16(float f) {
@@ -62,7 +102,7 @@ size_t blob_bytes_for(int F, int mode) {
   for (int s = 0; s < NUM_STAGES; ++s) {
     const StageDesc& d = stage_of(mode, s);
     int k8 = (s == ST_E0) ? e0_steps(mode, F) : d.k8;
-    units += (size_t)d.jobs * k8 * d.nb * 64;      // weights: float4 per lane
+    units += (size_t)d.jobs * k8 * d.nb * 64 * pieces_of(mode);      // weights: 16 bytes per lane (and piece)
     units += (size_t)d.jobs * d.nb * 2 * 4;        // bias: 2 halves x 16 floats
   }
   units += 4096;  // 64 KiB tail pad: the K loops prefetch up to 7 steps (<= 8 KiB) past a job's end
@@ -73,8 +113,9 @@ int pack_blob(int F, int mode, const float* const enc_w[6], const float* const e
               const float* const head_w[3][5], const float* const head_b[3][5],
               void* blob, size_t blob_bytes) {
   if (F <= 0 || !blob) return fail(NLML_E_BADARG, "pack: bad F or null blob");
-  const bool bf16 = mode == NLML_MODE_BF16;
-  const int kw = bf16 ? 16 : 8;        // K step width
+  const bool bf16 = mode == NLML_MODE_BF16, f16x2 = mode == NLML_MODE_F16X2;
+  const int kw = (bf16 || f16x2) ? 16 : 8;        // K step width
+  const int pieces = pieces_of(mode);
   const int per_half = kw / 2;         // k values per lane half
   const size_t need = blob_bytes_for(F, mode);
   if (blob_bytes < need) return fail(NLML_E_BADARG, "pack: blob buffer too small");
@@ -102,15 +143,38 @@ int pack_blob(int F, int mode, const float* const enc_w[6], const float* const e
   for (int s = 0; s < NUM_STAGES; ++s) {
     const StageDesc& d = stage_of(mode, s);
     const int k8 = (s == ST_E0) ? e0_steps(mode, F) : d.k8;
-    const size_t job_w16 = (size_t)k8 * d.nb * 64;
+    const size_t job_w16 = (size_t)k8 * d.nb * 64 * pieces;
     hdr->w_off[s] = (uint32_t)cur;
+    // split-f16 mode: one power-of-two scale per stage puts the largest |w| in [128, 256), so the lo pieces of all
+    // but the tiniest weights are normal f16 numbers; bias is scaled alike, the kernel multiplies by inv_scale.
+    float scale = 1.0f;
+    if (f16x2) {
+      float mx = 0.0f;
+      const int nmat = s <= ST_E5 ? 1 : 3;
+      for (int g = 0; g < nmat; ++g) {
+        const float* Wsrc = s <= ST_E5 ? enc_w[s] : head_w[g][s - ST_H0];
+        const size_t cnt = s <= ST_E5 ? (size_t)encN[s] * encK[s] : (size_t)headN[s - ST_H0] * headK[s - ST_H0];
+        for (size_t i = 0; i < cnt; ++i) {
+          const float a = std::fabs(Wsrc[i]);
+          if (a > mx && a <= 3.0e38f) mx = a;
+        }
+      }
+      if (mx > 0.0f) {
+        int ex = 0;
+        std::frexp(mx, &ex);                    // mx = m * 2^ex, m in [0.5, 1)
+        int e = 8 - ex;                         // mx * 2^e in [128, 256)
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        scale = std::ldexp(1.0f, e);
+      }
+    }
+    hdr->inv_scale[s] = 1.0f / scale;
     hdr->job_w16[s] = (uint32_t)job_w16;
     const size_t b_off = cur + (size_t)d.jobs * job_w16;
     hdr->b_off[s] = (uint32_t)b_off;
 
     for (int j = 0; j < d.jobs; ++j) {
       JobSrc src{};
-      src.lat_step = bf16 ? 16 : 8;
+      src.lat_step = (bf16 || f16x2) ? 16 : 8;
       if (s <= ST_E5) {
         src.W = enc_w[s]; src.b = enc_b[s]; src.K = encK[s]; src.N = encN[s];
         src.row0 = j * d.nb * 32;
@@ -128,12 +192,22 @@ int pack_blob(int F, int mode, const float* const enc_w[6], const float* const e
         for (int nb = 0; nb < d.nb; ++nb)
           for (int lane = 0; lane < 64; ++lane) {
             const int n = row_of(src, nb * 32 + (lane & 31));
-            float* dst = w + (((size_t)st * d.nb + nb) * 64 + lane) * 4;      // 16 bytes per lane
+            float* dst = w + ((((size_t)st * d.nb + nb) * pieces) * 64 + lane) * 4;      // 16 bytes per lane
             uint16_t* dst16 = reinterpret_cast<uint16_t*>(dst);
+            uint16_t* dst16_lo = dst16 + 64 * 8;                                        // piece 1 follows piece 0
             for (int e = 0; e < per_half; ++e) {
               const int k = kw * st + per_half * (lane >> 5) + e;
               const float v = (n >= 0 && k < src.K) ? src.W[(size_t)n * src.K + k] : 0.0f;
-              if (bf16) dst16[e] = to_bf16(v); else dst[e] = v;
+              if (f16x2) {
+                const float vs = v * scale;                       // exact: power of two
+                const uint16_t hi = to_f16(vs);
+                dst16[e] = hi;
+                dst16_lo[e] = to_f16(vs - from_f16(hi));          // the difference is exact in f32
+              } else if (bf16) {
+                dst16[e] = to_bf16(v);
+              } else {
+                dst[e] = v;
+              }
             }
           }
       float* b = base + (b_off + (size_t)j * d.nb * 8) * 4;
@@ -141,7 +215,7 @@ int pack_blob(int F, int mode, const float* const enc_w[6], const float* const e
         for (int h = 0; h < 2; ++h)
           for (int q = 0; q < 16; ++q) {
             const int n = row_of(src, nb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h);
-            b[(nb * 2 + h) * 16 + q] = n >= 0 ? src.b[n] : 0.0f;
+            b[(nb * 2 + h) * 16 + q] = n >= 0 ? src.b[n] * scale : 0.0f;
           }
     }
     cur = b_off + (size_t)d.jobs * d.nb * 8;

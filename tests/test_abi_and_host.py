@@ -43,6 +43,27 @@ def test_packed_blob_walk_matches_oracle(F, head_sds):
     assert np.abs(lat - EH.encoder_latent_numpy(x, P, np.float64)).max() <= 1e-12
 
 
+@pytest.mark.parametrize("F", [1404, 136, 13])
+def test_packed_blob_walk_split_f16_mode(F, head_sds):
+    """NLML_MODE_F16X2: the blob's hi+lo f16 weight pieces, per-stage power-of-two scale and scaled bias, walked with
+    the kernel's index arithmetic and its three-product formula, land within the parity bar of the f64 oracle."""
+    sd = synth.encoder_state_dict(F, seed=0)
+    blob = weights.pack_blob(sd, head_sds, _lib.MODE_F16X2)
+    L = _lib.lib()
+    sizes = {m: L.nlml_encoder_heads_packed_bytes(F, m) for m in (0, 1, 2)}
+    assert blob.nbytes == sizes[2] and len(set(sizes.values())) == 3, "modes are recognised by blob size"
+    hdr = BE._header(blob)
+    inv = hdr["inv_scale"]
+    assert np.all(np.log2(inv) == np.round(np.log2(inv))), "scales are powers of two"
+    x = synth.features(32, F, seed=5)
+    out, lat = BE.forward_f16x2(blob, x)
+    P = EH.Params(sd, head_sds)
+    ref = EH.forward_numpy(x, P, np.float64)
+    err_deg = np.abs(np.degrees(out - ref)).max()
+    assert err_deg <= 2e-5, err_deg                       # parity bar is 1e-4 deg; the split leaves ~1e-5
+    assert np.abs(lat - EH.encoder_latent_numpy(x, P, np.float64)).max() <= 2e-6
+
+
 def test_pack_rejects_bad_input(head_sds):
     sd = synth.encoder_state_dict(136, seed=0)
     bad = dict(sd)

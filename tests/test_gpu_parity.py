@@ -500,3 +500,124 @@ def test_graphed_video_tick_matches_eager(head_sds, device):
         torch.cuda.synchronize()
         assert torch.equal(sm_a, sm_b) and torch.equal(c_a, c_b) and torch.equal(ep_a, ep_b) and torch.equal(v_a, v_b)
     assert torch.equal(a.state, b.state)
+
+
+# ---- split-f16 parity mode (NLML_MODE_F16X2) ---------------------------------------------------------------------
+def _blob_hx(sd, head_sds, device):
+    from nlml_hpe_amd import _lib
+    return torch.from_numpy(weights.pack_blob(sd, head_sds, _lib.MODE_F16X2)).to(device)
+
+
+@pytest.mark.parametrize("F,B", [(1404, 1), (1404, 31), (1404, 33), (1404, 1000), (136, 77), (64, 50), (10, 40), (1407, 65)])
+def test_split_f16_mode_vs_oracle(F, B, head_sds, device):
+    """NLML_MODE_F16X2 is a PARITY mode: same 1e-4 degree bar as the f32 kernel (tolerance: POSE_TOL_DEG, absolute,
+    against the f64 arithmetic truth and against the f32 CPU restatement of the reference)."""
+    sd = synth.encoder_state_dict(F, seed=3)
+    x = synth.features(B, F, seed=9)
+    P = EH.Params(sd, head_sds)
+    ref64 = EH.forward_numpy(x, P, np.float64)
+    ref32 = EH.forward_numpy(x, P, np.float32)
+    lat64 = EH.encoder_latent_numpy(x, P, np.float64)
+    out, lat = ops.encoder_heads_fwd(torch.from_numpy(x).to(device), _blob_hx(sd, head_sds, device), F, return_latent=True)
+    out, lat = out.cpu().numpy(), lat.cpu().numpy()
+    e64 = np.degrees(np.abs(out - ref64).max())
+    e32 = np.degrees(np.abs(out - ref32).max())
+    _report(f"split_f16_vs_oracle_F{F}_B{B}", hip_vs_f64_deg=e64, hip_vs_f32_deg=e32, latent_abs=np.abs(lat - lat64).max())
+    assert e64 <= POSE_TOL_DEG and e32 <= POSE_TOL_DEG, (e64, e32)
+    assert np.abs(lat - lat64).max() <= 5e-6
+
+
+def test_split_f16_mode_golden_and_blob_walk(head_sds, golden_dir, device):
+    """FX3 golden vectors (generated by the reference itself) within the bar, and the kernel agrees with the numpy
+    walk of its own blob (tests/blob_emulator.py forward_f16x2: same pieces, same three products) far more tightly."""
+    import blob_emulator as BE
+    from nlml_hpe_amd import _lib
+    g = np.load(os.path.join(golden_dir, "fx3_encoder_heads.npz"))
+    for F in (1404, 136):
+        sd = synth.encoder_state_dict(F, seed=0)
+        x = synth.features(256, F, seed=1)
+        x[7] = 0.0
+        blob_np = weights.pack_blob(sd, head_sds, _lib.MODE_F16X2)
+        out, valid = ops.encoder_heads_fwd(torch.from_numpy(x).to(device), torch.from_numpy(blob_np).to(device), F, return_valid=True)
+        out = out.cpu().numpy()
+        err = np.degrees(np.abs(out - g[f"rad_F{F}"]).max())
+        emu, _ = BE.forward_f16x2(blob_np, x[32:64])
+        e_emu = np.degrees(np.abs(out[32:64] - emu).max())
+        _report(f"split_f16_fx3_F{F}", max_abs_deg=err, vs_blob_walk_deg=e_emu)
+        assert err <= POSE_TOL_DEG, err
+        assert e_emu <= 2e-5, e_emu            # f32 vs f64 accumulation of identical products
+        v = valid.cpu().numpy()
+        assert not v[7] and v.sum() == 255
+
+
+def test_split_f16_fused_landmarks_and_valid_mask(head_sds, device):
+    """Fused landmarks->pose in split-f16 mode: IPD normalisation stays exact (f64 division as in K1), so fused ==
+    normalise + forward bit for bit; validity mask and partial tiles as in the f32 mode."""
+    sd = synth.encoder_state_dict(1404, seed=0)
+    blob = _blob_hx(sd, head_sds, device)
+    raw = synth.raw_landmarks(131, seed=17)
+    raw[3] = np.array([0.25, 0.5, 0.75], np.float32)
+    raw[64] = 0.0
+    raw[130] = np.array([0.1, 0.1, 0.1], np.float32)
+    rt = torch.from_numpy(raw).to(device)
+    feats = ops.normalize_ipd(rt, True)
+    pose, valid = ops.landmarks_to_pose(rt, blob, True, return_valid=True)
+    ref_valid = ~FN.no_face_mask(FN.normalize_ipd(raw, True))
+    assert np.array_equal(valid.cpu().numpy(), ref_valid)
+    assert torch.equal(pose, ops.encoder_heads_fwd(feats, blob, 1404))
+    ok = torch.from_numpy(ref_valid).to(device)
+    ref = EH.forward_numpy(FN.normalize_ipd(raw, True), EH.Params(sd, head_sds), np.float64)
+    err = np.degrees(np.abs(pose.cpu().numpy() - ref)[ref_valid].max())
+    _report("split_f16_fused", max_abs_deg=err)
+    assert err <= POSE_TOL_DEG, err
+    unnorm = ops.landmarks_to_pose(rt, blob, False)
+    ref_u = EH.forward_numpy(FN.normalize_ipd(raw, False), EH.Params(sd, head_sds), np.float64)
+    assert np.degrees(np.abs(unnorm.cpu().numpy() - ref_u).max()) <= POSE_TOL_DEG
+    assert ok.sum() == 128
+
+
+def test_split_f16_full_batch_65536_properties(head_sds, device):
+    """BASELINE.json size in split-f16 mode: batch-position independence (bit-exact), sampled rows within 1e-4 deg of
+    the f64 oracle, and agreement with the f32 parity kernel on every one of the 65,536 faces within the same bar."""
+    F, B = 1404, 65536
+    sd = synth.encoder_state_dict(F, seed=0)
+    blob = _blob_hx(sd, head_sds, device)
+    x = synth.features(B, F, seed=42)
+    xt = torch.from_numpy(x).to(device)
+    full = ops.encoder_heads_fwd(xt, blob, F)
+    idx = synth.rng(42, 9).permutation(B)[:777]
+    it = torch.from_numpy(idx).to(device)
+    assert torch.equal(ops.encoder_heads_fwd(xt[it], blob, F), full[it])
+    ref = EH.forward_numpy(x[idx], EH.Params(sd, head_sds), np.float64)
+    err = np.degrees(np.abs(full[it].cpu().numpy() - ref).max())
+    f32 = ops.encoder_heads_fwd(xt, _blob(sd, head_sds, device), F)
+    d = torch.rad2deg((full - f32).abs()).max().item()
+    _report("split_f16_full_batch", sampled_vs_f64_deg=err, all_faces_vs_f32_kernel_deg=d)
+    assert err <= POSE_TOL_DEG and d <= POSE_TOL_DEG, (err, d)
+    assert torch.equal(ops.encoder_heads_fwd(xt[:B - 1], blob, F), full[:B - 1])
+
+
+def test_split_f16_nan_inf_and_f16_overflow_are_loud(head_sds, device):
+    """NaN/Inf stay in their face; an activation beyond f16's range (|x| >= 65520) makes THAT face's pose NaN -- never a
+    silently wrong number -- and leaves the other faces of the tile untouched."""
+    F = 1404
+    sd = synth.encoder_state_dict(F, seed=0)
+    blob = _blob_hx(sd, head_sds, device)
+    x = synth.features(200, F, seed=23)
+    clean = ops.encoder_heads_fwd(torch.from_numpy(x).to(device), blob, F)
+    bad = x.copy()
+    bad[5, 100] = np.nan
+    bad[70, 1403] = np.inf
+    bad[133, 0] = -np.inf
+    bad[150, 7] = 7.0e4               # finite in f32, beyond f16
+    bad[151, 7] = 6.0e4               # still inside f16: must stay finite and accurate
+    out = ops.encoder_heads_fwd(torch.from_numpy(bad).to(device), blob, F)
+    rows = torch.ones(200, dtype=torch.bool, device=device)
+    rows[[5, 70, 133, 150, 151]] = False
+    assert torch.equal(out[rows], clean[rows])
+    for r in (5, 70, 133, 150):
+        assert torch.isnan(out[r]).all() or not torch.isfinite(out[r]).all(), r
+    assert torch.isnan(out[150]).all()
+    ref = EH.forward_numpy(bad[151:152], EH.Params(sd, head_sds), np.float64)
+    rel = np.abs(out[151].cpu().numpy() - ref[0]) / np.maximum(1.0, np.abs(ref[0]))
+    assert torch.isfinite(out[151]).all() and rel.max() <= 1e-5
