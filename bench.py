@@ -7,15 +7,17 @@
 One STEP = one pass of the hot path over one batch that is already resident in HBM:
 raw landmarks f32[B,468,3] -> IPD normalisation -> encoder -> 3 heads -> (yaw,pitch,roll) f32[B,3],
 one fused HIP launch per rank (nlml_landmarks_to_pose), B = 65,536 faces per GPU (weak scaling),
-F = 1404 (the reference's real feature width), f32 parity mode.  With N > 1 every
+F = 1404 (the reference's real feature width).  --mode picks the parity kernel: f16x2 (default: split-f16
+operands on the f16 matrix cores, f32 accumulate, ~1e-5 deg from the reference) or f32 (f32 matrix cores).  With N > 1 every
 step also all-gathers the [B,3] poses of all ranks over RCCL (the only collective the path has),
 on the communication stream, overlapped with the next step's compute.
 
 Prints ONE JSON line (rank 0): the contract fields plus
-  roofline      the fused kernel against the dense f32-MFMA peak (the binding roofline),
+  roofline      the fused kernel against the dense MFMA peak of its operand type,
                 achieved = algorithmic FLOP per launch / average launch time from HIP events;
-  cpu_baseline  the oracle's torch-CPU restatement of the same arithmetic on this host's cores;
-  extra         secondary workloads (features-in K2, F=136, stand-alone K1, Tucker objective K3).
+  cpu_baseline  the oracle's torch-CPU restatement of the same arithmetic on this host's cores, plus
+                parity_check: the measured kernel's poses against the f64 oracle on a sample of the batch;
+  extra         the other K2 modes and secondary workloads (features-in K2, F=136, K1, K3, video, TD Powell).
 """
 from __future__ import annotations
 
@@ -36,6 +38,8 @@ FLOP_PER_FACE = {1404: 4_714_240, 136: 2_117_376}     # SURVEY.md section 8 tabl
 BYTES_PER_FACE_K2 = {1404: 5_628, 136: 556}            # f32 features in + 3 x f32 out
 BYTES_PER_FACE_K1 = 11_232                             # 5616 read + 5616 written
 PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md, dense f32 matrix
+PEAK_F16_MFMA_TFLOPS = 2500.0                          # MI355X_MICROARCH.md, dense bf16/f16 MFMA
+SPLIT_PRODUCTS = 3                                     # f16x2 mode: hi*hi + hi*lo + lo*hi per algorithmic product
 PEAK_HBM_GBS = 8000.0
 PEAK_F64_TFLOPS = 78.6
 TUCKER_FLOP_PER_EVAL = 383_700
@@ -49,6 +53,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=65536, help="faces per GPU per step")
     ap.add_argument("--path", choices=["fused", "features"], default="fused",
                     help="fused: raw landmarks in (K1+K2 in one launch); features: normalised features in (K2)")
+    ap.add_argument("--mode", choices=["f16x2", "f32"], default="f16x2",
+                    help="parity kernel: f16x2 = split-f16 operands on the f16 matrix cores; f32 = f32 matrix cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -101,7 +107,9 @@ def main():
     F, B = 1404, args.batch
     heads = weights.load_head_state_dicts(os.path.join(ROOT, "models"))
     sd = synth.encoder_state_dict(F, seed=0)
-    blob = torch.from_numpy(weights.pack_blob(sd, heads)).to(dev)
+    from nlml_hpe_amd import _lib
+    mode = _lib.MODE_F16X2 if args.mode == "f16x2" else _lib.MODE_F32
+    blob = torch.from_numpy(weights.pack_blob(sd, heads, mode)).to(dev)
     raw_np = synth.raw_landmarks(B, seed=1 + rank)           # each rank owns its own shard of faces
     raw = torch.from_numpy(raw_np).to(dev)
     feats = ops.normalize_ipd(raw, True)
@@ -157,28 +165,42 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{args.path}_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(f"{args.mode}_{args.path}_bytes_per_launch")
             except Exception:
                 traffic = None
+        if args.mode == "f16x2":
+            peak, kernel = PEAK_F16_MFMA_TFLOPS, "encoder_heads_f16x2_kernel"
+            roof_extra = {"executed_flop_per_launch": SPLIT_PRODUCTS * B * FLOP_PER_FACE[F],
+                          "executed_frac": SPLIT_PRODUCTS * achieved / peak,
+                          "note": "each algorithmic product runs as 3 f16 MFMA products (hi*hi + hi*lo + lo*hi, f32 accumulate); "
+                                  "frac counts the algorithmic FLOP only; the kernel is limited by the L2->CU weight stream and "
+                                  "stage prologues, not by the matrix pipe (DESIGN.md)"}
+            dtype = "f16x2"
+            what = "split-f16 parity mode (two f16 pieces per f32 operand, f32 accumulate)"
+        else:
+            peak, kernel, roof_extra, dtype, what = PEAK_F32_MFMA_TFLOPS, "encoder_heads_f32_kernel", {}, "f32", "f32 parity mode"
         rec = {
             "metric": "faces_per_sec", "value": value, "unit": "faces/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: gloo, shared devices -- not a measurement)",
             "config": {"workload": f"landmarks->pose, batch {B}/GPU, F=1404 (468x3 landmarks), encoder+3 heads fused HIP forward, "
-                                   f"f32 parity mode, path={args.path}",
-                       "faces_per_gpu": B, "F": F, "path": args.path, "seeds": {"encoder": 0, "landmarks": "1+rank"},
+                                   f"{what}, path={args.path}",
+                       "faces_per_gpu": B, "F": F, "path": args.path, "mode": args.mode,
+                       "seeds": {"encoder": 0, "landmarks": "1+rank"},
                        "collective": "all_gather f32[B,3] per step" if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "encoder_heads_f32_kernel", "kernel_ms": kern_ms,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
+                         "kernel": kernel, "kernel_ms": kern_ms,
                          "flop_per_launch": B * FLOP_PER_FACE[F],
-                         "hbm_frac": B * (BYTES_PER_FACE_K2[F]) / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                         "hbm_frac": B * (BYTES_PER_FACE_K2[F]) / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, **roof_extra},
         }
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(raw_np, sd, heads, args.cpu_seconds)
+            sample = np.arange(0, B, max(1, B // 2048))[:2048]
+            got = step_fn()[torch.from_numpy(sample).to(dev)].cpu().numpy()
+            rec["cpu_baseline"] = cpu_baseline(raw_np, sd, heads, args.cpu_seconds, sample, got)
         if world == 1 and not args.no_extra:
-            rec["extra"] = extra_workloads(ops, synth, weights, dev, heads, blob, raw, feats, B)
+            rec["extra"] = extra_workloads(ops, synth, weights, dev, heads, sd, raw, feats, B)
         print(json.dumps(rec), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -208,8 +230,9 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(raw_np, sd, heads, seconds):
-    """The oracle ("port": same ATen ops as the reference's CPU path) on this host's cores."""
+def cpu_baseline(raw_np, sd, heads, seconds, sample, got):
+    """The oracle ("port": same ATen ops as the reference's CPU path) on this host's cores; `got` = the timed kernel's
+    poses for rows `sample`, checked here against the f64 oracle (the only place bench.py touches oracle/)."""
     from oracle import encoder_heads as EH
     from oracle import feature_norm as FN
     ncores = usable_cores()
@@ -229,31 +252,50 @@ def cpu_baseline(raw_np, sd, heads, seconds):
     for i in range(64):                                  # the way the reference actually runs: batch 1
         EH.forward_torch(x[i:i + 1], P)
     b1 = 64 / (time.perf_counter() - t1)
+    truth = EH.forward_numpy(FN.normalize_ipd(raw_np[sample], True), P, np.float64)
+    err = np.degrees(np.abs(got.astype(np.float64) - truth))
     return {"value": done / dt, "unit": "faces/s", "cores": ncores, "kind": "port",
             "sample": f"{done} faces in batches of {n} (encoder+heads on pre-normalised rows, torch CPU f32, {dt:.1f} s)",
-            "batch1_faces_per_sec": b1}
+            "batch1_faces_per_sec": b1,
+            "parity_check": {"faces": int(len(sample)), "max_abs_deg_vs_f64_oracle": float(err.max()),
+                             "mean_abs_deg": float(err.mean()), "tolerance_deg": 1e-4}}
 
 
-def extra_workloads(ops, synth, weights, dev, heads, blob, raw, feats, B):
-    ex = {}
-    ms = time_kernel(lambda: ops.encoder_heads_fwd(feats, blob, 1404), 10)
-    ex["k2_features_F1404"] = {"faces_per_sec": B / ms * 1e3, "tflops": B * FLOP_PER_FACE[1404] / ms / 1e9,
-                               "mfma_frac": B * FLOP_PER_FACE[1404] / ms / 1e9 / PEAK_F32_MFMA_TFLOPS}
-    sd136 = synth.encoder_state_dict(136, seed=0)
-    blob136 = torch.from_numpy(weights.pack_blob(sd136, heads)).to(dev)
-    x136 = torch.from_numpy(synth.features(B, 136, seed=1)).to(dev)
-    ms = time_kernel(lambda: ops.encoder_heads_fwd(x136, blob136, 136), 10)
-    ex["k2_features_F136"] = {"faces_per_sec": B / ms * 1e3, "tflops": B * FLOP_PER_FACE[136] / ms / 1e9,
-                              "mfma_frac": B * FLOP_PER_FACE[136] / ms / 1e9 / PEAK_F32_MFMA_TFLOPS}
-    # throughput mode (bf16 operands, f32 accumulate): NOT a parity result -- its measured error is reported with it
+def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     from nlml_hpe_amd import _lib
-    sd1404 = synth.encoder_state_dict(1404, seed=0)
+    ex = {}
+    blob = torch.from_numpy(weights.pack_blob(sd1404, heads, _lib.MODE_F32)).to(dev)
+    blob_hx = torch.from_numpy(weights.pack_blob(sd1404, heads, _lib.MODE_F16X2)).to(dev)
+    sd136 = synth.encoder_state_dict(136, seed=0)
+    x136 = torch.from_numpy(synth.features(B, 136, seed=1)).to(dev)
+
+    def k2(fn, F, peak, products=1):
+        ms = time_kernel(fn, 10)
+        tf = B * FLOP_PER_FACE[F] / ms / 1e9
+        d = {"faces_per_sec": B / ms * 1e3, "tflops": tf, "mfma_frac": tf / peak}
+        if products > 1:
+            d["executed_frac"] = products * tf / peak
+        return d
+
+    # f32 parity kernel (f32 matrix cores; the MFMA-bound formulation)
+    ex["k2_f32_fused_F1404"] = k2(lambda: ops.landmarks_to_pose(raw, blob, True), 1404, PEAK_F32_MFMA_TFLOPS)
+    ex["k2_f32_features_F1404"] = k2(lambda: ops.encoder_heads_fwd(feats, blob, 1404), 1404, PEAK_F32_MFMA_TFLOPS)
+    blob136 = torch.from_numpy(weights.pack_blob(sd136, heads, _lib.MODE_F32)).to(dev)
+    ex["k2_f32_features_F136"] = k2(lambda: ops.encoder_heads_fwd(x136, blob136, 136), 136, PEAK_F32_MFMA_TFLOPS)
+    # split-f16 parity kernel (f16 matrix cores, three products per algorithmic product)
+    ex["k2_f16x2_fused_F1404"] = k2(lambda: ops.landmarks_to_pose(raw, blob_hx, True), 1404, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
+    ex["k2_f16x2_features_F1404"] = k2(lambda: ops.encoder_heads_fwd(feats, blob_hx, 1404), 1404, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
+    blob136_hx = torch.from_numpy(weights.pack_blob(sd136, heads, _lib.MODE_F16X2)).to(dev)
+    ex["k2_f16x2_features_F136"] = k2(lambda: ops.encoder_heads_fwd(x136, blob136_hx, 136), 136, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
+    d = torch.rad2deg((ops.landmarks_to_pose(raw, blob_hx, True) - ops.landmarks_to_pose(raw, blob, True)).abs())
+    ex["k2_f16x2_vs_f32_kernel_all_faces"] = {"max_abs_deg": float(d.max()), "mean_abs_deg": float(d.mean()), "faces": B}
+    # throughput mode (bf16 operands, f32 accumulate): NOT a parity result -- its measured error is reported with it
     blob_bf = torch.from_numpy(weights.pack_blob(sd1404, heads, _lib.MODE_BF16)).to(dev)
     ms = time_kernel(lambda: ops.landmarks_to_pose(raw, blob_bf, True), 10)
     sub = slice(0, 4096)
     d = (ops.landmarks_to_pose(raw[sub], blob_bf, True) - ops.landmarks_to_pose(raw[sub], blob, True)).abs()
     ex["k2_bf16_throughput_mode"] = {"faces_per_sec": B / ms * 1e3, "tflops": B * FLOP_PER_FACE[1404] / ms / 1e9,
-                                     "bf16_mfma_frac": B * FLOP_PER_FACE[1404] / ms / 1e9 / 2500.0,
+                                     "bf16_mfma_frac": B * FLOP_PER_FACE[1404] / ms / 1e9 / PEAK_F16_MFMA_TFLOPS,
                                      "max_abs_deg_vs_f32_mode": float(torch.rad2deg(d.max())),
                                      "mean_abs_deg_vs_f32_mode": float(torch.rad2deg(d.mean())),
                                      "note": "throughput mode; fails the 1e-4 deg parity bar by design (SURVEY D3)"}
@@ -304,12 +346,8 @@ def extra_workloads(ops, synth, weights, dev, heads, blob, raw, feats, B):
         ex[f"video_64_streams_{label}"] = {"tick_ms_p50": float(np.percentile(lat, 50) * 1e3), "tick_ms_p99": float(np.percentile(lat, 99) * 1e3),
                                            "faces_per_sec_sustained": S / float(lat.mean()), "offered_load_faces_per_sec": 64 * 30}
     # TD end-to-end (TD_Tester.Test): device-side lock-step Powell, one minimisation per face
-    from oracle import tucker as TK    # test-infra helper only used to synthesise grid faces (inputs), not measured
     idx = synth.tucker_grid_indices(4096, seed=2)     # BASELINE.json config 3: 4,096 faces
-    Xg = np.stack([TK.grid_reconstruction(art["W"], art["U_id"][i], art["U_yaw"][j], art["U_pitch"][k], art["U_roll"][l])
-                   for i, j, k, l in idx])
-    Xg = (Xg.astype(np.float64) + 1e-3 * synth.rng(2, 77).standard_normal(Xg.shape)).astype(np.float32)
-    Xg = torch.from_numpy(Xg).to(dev)
+    Xg = torch.from_numpy(synth.tucker_grid_faces(art, idx, 1e-3, seed=2)).to(dev)
     ops.tucker_powell(Wm, Xg[:64], cp)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

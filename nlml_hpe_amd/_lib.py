@@ -43,6 +43,18 @@ SYMBOLS = {
 MODE_F32 = 0
 MODE_BF16 = 1
 MODE_F16X2 = 2
+MODE_NAMES = {"f32": MODE_F32, "bf16": MODE_BF16, "f16x2": MODE_F16X2}
+
+
+def mode_from_name(mode) -> int:
+    """Accepts a NLML_MODE_* constant or its name ("f32", "bf16", "f16x2")."""
+    if isinstance(mode, str):
+        if mode not in MODE_NAMES:
+            raise ValueError(f"unknown mode {mode!r}; expected one of {sorted(MODE_NAMES)}")
+        return MODE_NAMES[mode]
+    if int(mode) not in MODE_NAMES.values():
+        raise ValueError(f"unknown mode {mode!r}")
+    return int(mode)
 
 _lib = None
 

@@ -20,20 +20,23 @@ def load_config(path: str) -> dict:
 
 
 def resolve_model(device, scripted_name: str = "models/combined_model_scripted.pth", model_dir: str = "models",
-                  input_size: int | None = None, synthetic_seed: int | None = 0) -> HIPPoseModel:
+                  input_size: int | None = None, synthetic_seed: int | None = 0, mode=None) -> HIPPoseModel:
     """The scripted file the reference loads if present; else the per-network state dicts; the encoder
-    falls back to SYNTHETIC weights (with a warning) because the reference ships no models/Encoder.pth."""
+    falls back to SYNTHETIC weights (with a warning) because the reference ships no models/Encoder.pth.
+    mode: "f32" (default), "f16x2" or "bf16" (model.HIPPoseModel); the NLML_HPE_MODE environment variable
+    sets it for the entry-point scripts without touching their command lines."""
+    mode = mode if mode is not None else os.environ.get("NLML_HPE_MODE", "f32")
     if os.path.isfile(scripted_name):
-        return load_model(scripted_name, device)
+        return load_model(scripted_name, device, mode=mode)
     try:
-        return load_model(model_dir, device)
+        return load_model(model_dir, device, mode=mode)
     except FileNotFoundError:
         if synthetic_seed is None:
             raise
         F = int(input_size or synth.F_REFERENCE)
         warnings.warn(f"{model_dir}/Encoder.pth not found: using SYNTHETIC encoder weights (seed {synthetic_seed}); "
                       "poses are numerically valid but not trained predictions")
-        return load_model(model_dir, device, encoder_state_dict=synth.encoder_state_dict(F, synthetic_seed))
+        return load_model(model_dir, device, encoder_state_dict=synth.encoder_state_dict(F, synthetic_seed), mode=mode)
 
 
 def load_landmarks(path: str) -> np.ndarray:

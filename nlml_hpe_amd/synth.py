@@ -96,6 +96,17 @@ def tucker_grid_indices(n: int, shape=(1620, 11, 9, 7), seed: int = 2) -> np.nda
     return np.stack([g.integers(0, s, size=n) for s in shape], axis=1)
 
 
+def tucker_grid_faces(art: dict, idx: np.ndarray, noise: float = 1e-3, seed: int = 2) -> np.ndarray:
+    """f32[N,1404] training-grid faces W x1 U_id[i] x2 U_yaw[j] x3 U_pitch[k] x4 U_roll[l] plus N(0, noise) --
+    the synthetic inputs of BASELINE.json config 3."""
+    W = np.asarray(art["W"], np.float64).reshape(5, 3, 3, 3, -1)
+    i, j, k, l = idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]
+    c = np.einsum("na,nb,nc,nd->nabcd", np.asarray(art["U_id"], np.float64)[i], np.asarray(art["U_yaw"], np.float64)[j],
+                  np.asarray(art["U_pitch"], np.float64)[k], np.asarray(art["U_roll"], np.float64)[l])
+    X = (c.reshape(len(idx), -1) @ W.reshape(135, -1)).astype(np.float32)
+    return (X.astype(np.float64) + noise * rng(seed, 77).standard_normal(X.shape)).astype(np.float32)
+
+
 def poses_deg(n: int, seed: int = 4) -> np.ndarray:
     """f64[N,3] smooth-ish ground-truth poses in degrees inside the reference's bin ranges."""
     g = rng(seed, _STREAM_POSE)

@@ -17,7 +17,9 @@ import sys
 from collections import defaultdict
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-path_key = sys.argv[2] if len(sys.argv) > 2 else "fused"
+path_key = sys.argv[2] if len(sys.argv) > 2 else "f16x2_fused"      # <mode>_<path> of the profiled bench.py run
+traffic_tag = sys.argv[3] if len(sys.argv) > 3 else "r01"           # bench.py reads profiles/r01_pmc_traffic.json
+bench_args = sys.argv[4] if len(sys.argv) > 4 else ""
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
@@ -64,7 +66,7 @@ for k, cs in counters.items():
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
 
 with open(os.path.join(dst, f"{tag}_pmc_summary.md"), "w") as f:
-    f.write(f"# rocprofv3 summary {tag}\n\nCommand: `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra` "
+    f.write(f"# rocprofv3 summary {tag}\n\nCommand: `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra {bench_args}` "
             "(kernel trace and each --pmc group in separate passes; tools/profile_gpu.sh).\n\n")
     for k, d in summary.items():
         f.write(f"## {k}\n\n")
@@ -78,10 +80,10 @@ with open(os.path.join(dst, f"{tag}_pmc_summary.md"), "w") as f:
 
 dom = max(summary, key=lambda k: summary[k].get("avg_duration_ns_trace", 0) * summary[k]["launches_profiled"]) if summary else None
 if dom and "hbm_bytes_per_launch_corrected" in summary[dom]:
-    tp = os.path.join(dst, f"{tag}_pmc_traffic.json")
+    tp = os.path.join(dst, f"{traffic_tag}_pmc_traffic.json")
     cur = json.load(open(tp)) if os.path.exists(tp) else {}
     cur[f"{path_key}_bytes_per_launch"] = summary[dom]["hbm_bytes_per_launch_corrected"]
-    cur["kernel"] = dom
+    cur[f"{path_key}_kernel"] = dom
     cur["correction"] = "(2*FETCH_SIZE + WRITE_SIZE) * 1024, MI355X_MICROARCH.md HBM section"
     json.dump(cur, open(tp, "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_pmc_summary.md")).read())
