@@ -98,6 +98,33 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[NB][NFB], const h8 (&w)[N
   }
 }
 
+// One K step of the 4x2 shape (24 MFMAs = 768 cycles) cut into six sub-groups of four MFMAs; everything else the step
+// has to issue -- the eight weight loads of the step D ahead (gaps 0-3, one neuron block each), the LDS reads of the
+// next step's x operands (gap 4) and whatever the caller drops into gap j through `between(j)` (layer 0: a piece of
+// the x staging) -- goes into the gaps, so that no block of non-MFMA instructions idles the matrix pipe for its whole
+// length (stage stamps: a 24-MFMA step with all of it in front ran at 55 % busy in layer 0).
+template <typename XLoad, typename Between>
+__device__ __forceinline__ void step_il(f32x16 (&acc)[4][2], const h8 (&wcur)[4][2], const h8 (&xcur)[2][2],
+                                        h8 (&wnext)[4][2], const h8* __restrict__ wp, XLoad xload, Between between) {
+#pragma unroll
+  for (int g = 0; g < 6; ++g) {
+    if (g < 4) {
+      wnext[g][0] = wp[(g * 2 + 0) * 64];
+      wnext[g][1] = wp[(g * 2 + 1) * 64];
+    }
+    if (g == 4) xload();
+    between(g);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 4 * g; m < 4 * g + 4; ++m) {
+      const int t = m / 8, nb = (m % 8) / 2, fb = m % 2;
+      const int wp_ = t == 0 ? 1 : 0, xp_ = t == 1 ? 1 : 0;   // (lo,hi), (hi,lo), (hi,hi)
+      acc[nb][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[nb][wp_], xcur[fb][xp_], acc[nb][fb], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // K loop over an LDS-resident hi/lo image; K16 static, no runtime branch in the body (see the f32 kernel).
 // `w`: this lane's hi fragment of block 0, step 0 (fragment (step, nb, piece) at ((step*NB + nb)*2 + piece)*64);
 // `in`: this lane's (face row of block 0, k = 8h) in the hi plane; the lo plane is `plane` bytes further.
@@ -120,6 +147,21 @@ __device__ __forceinline__ void kloop(f32x16 (&acc)[NB][NFB], const h8* __restri
 #pragma unroll
     for (int p = 0; p < 2; ++p) xr[0][fb][p] = *reinterpret_cast<const h8*>(in + p * plane + fb * fb_stride);
   auto step = [&](int r, int xs, int sp, int sx, bool prefetch) {
+    const int sxc = sx < K16 ? sx : K16 - 1;
+    if constexpr (NB == 4 && NFB == 2) {
+      if (prefetch) {
+        step_il(acc, wr[r], xr[xs], wr[(r + D) % R], w + (size_t)sp * (NB * 2 * 64),
+                [&]() {
+#pragma unroll
+                  for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                      xr[xs ^ 1][fb][p] = *reinterpret_cast<const h8*>(in + p * plane + fb * fb_stride + 32 * sxc);
+                },
+                [](int) {});
+        return;
+      }
+    }
     if (prefetch) {
       const h8* wp = w + (size_t)sp * (NB * 2 * 64);
 #pragma unroll
@@ -127,7 +169,6 @@ __device__ __forceinline__ void kloop(f32x16 (&acc)[NB][NFB], const h8* __restri
 #pragma unroll
         for (int p = 0; p < 2; ++p) wr[(r + D) % R][nb][p] = wp[(nb * 2 + p) * 64];
     }
-    const int sxc = sx < K16 ? sx : K16 - 1;
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
@@ -308,39 +349,52 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
       }
     }
   };
-  auto lwrite = [&](int buf_off, f32x4 (&st)[2], bool real_slab) {
+  // staging of one slab in pieces (one per MFMA gap of the slab's first K step; lwrite() = all of them, prologue)
+  auto lw_begin = [&](f32x4 (&st)[2]) {   // the set's loads must have landed: everything below consumes them
 #pragma unroll
     for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(st[i]));
+  };
+  auto lw_norm = [&](f32x4 (&st)[2], int j) {   // elements 2j, 2j+1 (j static)
+#pragma unroll
+    for (int q = 2 * j; q < 2 * j + 2; ++q) {
+      const int t = q % 3;
+      const double rr = t == 0 ? ra : (t == 1 ? rb : rc);
+      st[q / 4][q % 4] = (float)div_ipd((double)st[q / 4][q % 4] - rr, ipd, rcp);
+    }
+  };
+  auto lw_rotate = [&]() {   // next slab: columns + 32 => phase + 2
+    const double t0 = rc; rc = rb; rb = ra; ra = t0;
+  };
+  h8 pend_hi, pend_lo;
+  auto lw_split = [&](f32x4 (&st)[2], int i, bool real_slab) {   // half i of the 8 elements -> hi/lo f16
+    // the f32 value must exist as such: without this fence hipcc 7.2 folds (f16)(f32)double into ONE f64 -> f16
+    // conversion, done in ~20 integer instructions per element and rounded differently from the two-step path
+    asm volatile("" : "+v"(st[i]));
+    const unsigned m = real_slab ? 0x7fffffffu : 0u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = st[i][e];
+      nzbits |= __float_as_uint(v) & m;
+      const _Float16 hv = (_Float16)v;
+      pend_hi[4 * i + e] = hv;
+      pend_lo[4 * i + e] = (_Float16)(v - (float)hv);
+    }
+  };
+  auto lw_store = [&](int buf_off) {
+    char* d = c.lds + O_XS + buf_off + (srow * S_XS + scol) * 2;
+    *reinterpret_cast<h8*>(d) = pend_hi;
+    *reinterpret_cast<h8*>(d + P_XS) = pend_lo;
+  };
+  auto lwrite = [&](int buf_off, f32x4 (&st)[2], bool real_slab) {
+    lw_begin(st);
     if (NORM) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int t = (4 * i + e) % 3;
-          const double rr = t == 0 ? ra : (t == 1 ? rb : rc);
-          st[i][e] = (float)div_ipd((double)st[i][e] - rr, ipd, rcp);
-        }
-      // the f32 value must exist as such: without this fence hipcc 7.2 folds (f16)(f32)double into ONE f64 -> f16
-      // conversion, done in ~20 integer instructions per element and rounded differently from the two-step path
-#pragma unroll
-      for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(st[i]));
-      const double t0 = rc; rc = rb; rb = ra; ra = t0;   // next slab: columns + 32 => phase + 2
+      for (int j = 0; j < 4; ++j) lw_norm(st, j);
+      lw_rotate();
     }
-    const unsigned m = real_slab ? 0x7fffffffu : 0u;
-    h8 hi, lo;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = st[i][e];
-        nzbits |= __float_as_uint(v) & m;
-        const _Float16 hv = (_Float16)v;
-        hi[4 * i + e] = hv;
-        lo[4 * i + e] = (_Float16)(v - (float)hv);
-      }
-    char* d = c.lds + O_XS + buf_off + (srow * S_XS + scol) * 2;
-    *reinterpret_cast<h8*>(d) = hi;
-    *reinterpret_cast<h8*>(d + P_XS) = lo;
+    lw_split(st, 0, real_slab);
+    lw_split(st, 1, real_slab);
+    lw_store(buf_off);
   };
 
   const int job = 4 * pass + c.wv;
@@ -383,28 +437,29 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
     constexpr int PAR = decltype(par_c)::value;
     const char* xrow = c.lds + O_XS + o0 + lane_off;
     const char* xnext = c.lds + O_XS + o1 + lane_off;
+    const bool real = s + 2 < nslab;
 #pragma unroll
     for (int kk = 0; kk < XS_STEPS; ++kk) {
       const int slot = 2 * PAR + kk;
-      const h8* wp = w + (size_t)(s * XS_STEPS + kk + D0) * (NB * 2 * 64);
+      step_il(acc, wr[slot], xr[kk & 1], wr[(slot + D0) % R0], w + (size_t)(s * XS_STEPS + kk + D0) * (NB * 2 * 64),
+              [&]() {
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+                for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) wr[(slot + D0) % R0][nb][pp] = wp[(nb * 2 + pp) * 64];
-#pragma unroll
-      for (int fb = 0; fb < NFB; ++fb)
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp)
-          xr[(kk + 1) & 1][fb][pp] = (kk + 1 < XS_STEPS)
-                                         ? *reinterpret_cast<const h8*>(xrow + pp * P_XS + fb * FB + 32 * (kk + 1))
-                                         : *reinterpret_cast<const h8*>(xnext + pp * P_XS + fb * FB);
-      if (kk == 0) {
-        lwrite(o2, set[PAR], s + 2 < nslab);
-        gload(s + 4, set[PAR]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mma_step<NB, NFB>(acc, wr[slot], xr[kk & 1]);
-      __builtin_amdgcn_sched_barrier(0);
+                  for (int pp = 0; pp < 2; ++pp)
+                    xr[(kk + 1) & 1][fb][pp] = (kk + 1 < XS_STEPS)
+                                                   ? *reinterpret_cast<const h8*>(xrow + pp * P_XS + fb * FB + 32 * (kk + 1))
+                                                   : *reinterpret_cast<const h8*>(xnext + pp * P_XS + fb * FB);
+              },
+              [&](int g) {   // slab s+2's staging, one piece per gap: step 0 normalises, step 1 splits, stores, reloads
+                if (kk == 0 && g == 0) lw_begin(set[PAR]);
+                if (NORM && kk == 0 && g >= 1 && g <= 4) lw_norm(set[PAR], g - 1);
+                if (NORM && kk == 0 && g == 5) lw_rotate();
+                if (kk == 1 && g == 0) lw_split(set[PAR], 0, real);
+                if (kk == 1 && g == 1) lw_split(set[PAR], 1, real);
+                if (kk == 1 && g == 2) lw_store(o2);
+                if (kk == 1 && g == 3) gload(s + 4, set[PAR]);
+              });
     }
     __syncthreads();
     const int t0 = o0;   // rotate: (o0, o1, o2) <- (o1, o2, o0)
@@ -419,6 +474,24 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
     if ((tid & 3) == 0 && live) a.valid[row0 + srow] = ((m >> (c.lane & 60)) & 0xFull) ? 1 : 0;
   }
 }
+
+// Timing-only diagnostic build (-DHX_STAMPS, tools/hx_stage_shares.py): per-wave s_memtime stamps at the stage
+// boundaries are written into the buffer passed as `latent` (which then carries no latent).
+#ifdef HX_STAMPS
+#define HXS(i)                                                                                                 \
+  do {                                                                                                         \
+    if (a.latent && c.lane == 0)                                                                               \
+      reinterpret_cast<unsigned long long*>(a.latent)[((size_t)blockIdx.x * 4 + wv) * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define HXS_WALL(i)                                                                                            \
+  do {                                                                                                         \
+    if (a.latent && c.lane == 0)                                                                               \
+      reinterpret_cast<unsigned long long*>(a.latent)[((size_t)blockIdx.x * 4 + wv) * 32 + (i)] = __builtin_readcyclecounter() * 0 + wall_clock64(); \
+  } while (0)
+#else
+#define HXS(i) do { } while (0)
+#define HXS_WALL(i) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------
 template <bool VEC4, bool NORM>
@@ -443,22 +516,29 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
     load_bias<4, 2>(acc1, c.blob4 + c.hdr->b_off[ST_E1] + wv * (4 * 8), c.h);
     const h8* w1 = c.blob8 + c.hdr->w_off[ST_E1] + (size_t)wv * c.hdr->job_w16[ST_E1] + c.lane;
     const float inv0 = c.hdr->inv_scale[ST_E0];
+    HXS(0);
+    HXS_WALL(30);
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       {
         f32x16 acc0[4][2];
         stage_e0_pass<VEC4, NORM>(c, a, row0, tid, pass, acc0);
+        HXS(1 + 4 * pass);
         // the last barrier of the slab loop also says: every wave is done reading H1H (previous pass's E1 half)
         job_store<4, 2, ACT_RELU>(c, acc0, O_H1H, P_H1H, S_H1H, 128 * wv, 0, inv0);
       }
       __syncthreads();
+      HXS(2 + 4 * pass);
       kloop<4, 2, 32>(acc1, w1 + (size_t)pass * 32 * (4 * 2 * 64), c.lds + O_H1H + (c.f * S_H1H + 8 * c.h) * 2, P_H1H,
                       32 * S_H1H * 2);
+      HXS(3 + 4 * pass);
       __syncthreads();   // H1H is free again (pass 0: for pass 1's store; pass 1: for H2)
+      HXS(4 + 4 * pass);
     }
     job_store<4, 2, ACT_RELU>(c, acc1, O_H2, P_H2, S_H2, 128 * wv, 0, c.hdr->inv_scale[ST_E1]);
   }
   __syncthreads();
+  HXS(9);
   {  // E2: 512 -> 256, ReLU; h3 overwrites h2 => barrier between the K loop and the store
     f32x16 acc[2][2];
     job_compute<2, 2, ST_E2>(c, wv, acc, O_H2, P_H2, S_H2, 0, 0);
@@ -466,12 +546,14 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
     job_store<2, 2, ACT_RELU>(c, acc, O_H3, P_H3, S_H3, 64 * wv, 0, c.hdr->inv_scale[ST_E2]);
   }
   __syncthreads();
+  HXS(10);
   {  // E3: 256 -> 128, ReLU
     f32x16 acc[1][2];
     job_compute<1, 2, ST_E3>(c, wv, acc, O_H3, P_H3, S_H3, 0, 0);
     job_store<1, 2, ACT_RELU>(c, acc, O_H4, P_H4, S_H4, 32 * wv, 0, c.hdr->inv_scale[ST_E3]);
   }
   __syncthreads();
+  HXS(11);
   {  // E4: 128 -> 64, Tanh; neuron block wv&1, face block wv>>1
     const int nb = wv & 1, face0 = 32 * (wv >> 1);
     f32x16 acc[1][1];
@@ -483,6 +565,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
     f32x16 acc[2][1];
     job_compute<2, 1, ST_E5>(c, 0, acc, O_H5, P_H5, S_H5, 0, 32 * wv);
     const float inv = c.hdr->inv_scale[ST_E5];
+#ifndef HX_STAMPS
     if (a.latent && row0 + 32 * wv + c.f < a.B) {   // f32 latent straight from the accumulators
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
@@ -492,9 +575,11 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
           if (g < 3 && cc < 3) a.latent[(row0 + 32 * wv + c.f) * NLML_LATENT + 3 * g + cc] = acc[nb][0][q] * inv;
         }
     }
+#endif
     job_store<2, 1, ACT_NONE, S_LAT>(c, acc, O_LAT, P_LAT, S_LAT, 0, 32 * wv, inv);
   }
   __syncthreads();
+  HXS(12);
   // ---- heads, one 32-face block at a time; the jobs a wave owns run together (kloop_grouped)
 #pragma unroll 1
   for (int fb = 0; fb < 2; ++fb) {
@@ -519,6 +604,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
       }
     }
     __syncthreads();
+    HXS(13 + 5 * fb);
     {  // H1: 128 -> 256, ReLU
       constexpr int ST = ST_H1;
       f32x16 acc[3][2][1];
@@ -539,6 +625,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
       }
     }
     __syncthreads();
+    HXS(14 + 5 * fb);
     {  // H2: 256 -> 128, ReLU
       constexpr int ST = ST_H2;
       f32x16 acc[3][1][1];
@@ -559,6 +646,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
       }
     }
     __syncthreads();
+    HXS(15 + 5 * fb);
     if (wv < 3) {  // H3: 128 -> 64, ReLU: waves 0..2 take the two blocks of head wv
       constexpr int ST = ST_H3;
       f32x16 acc[2][1][1];
@@ -576,13 +664,16 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
         store_lds<1, 1, ACT_RELU>(acc[j], c.lds + O_HD + (c.f * S_HD + 64 * wv + 32 * j + 4 * c.h) * 2, P_HD, 0, inv);
     }
     __syncthreads();
+    HXS(16 + 5 * fb);
     if (wv < 3) {  // H4: 64 -> 1; neuron on accumulator row 0 = register 0 of lanes 0..31
       f32x16 acc[1][1];
       job_compute<1, 1, ST_H4>(c, wv, acc, O_HD, P_HD, S_HD, 64 * wv, 0);
       if (c.h == 0 && row0 + face0 + c.f < a.B) a.out[(row0 + face0 + c.f) * 3 + wv] = acc[0][0][0] * c.hdr->inv_scale[ST_H4];
     }
     __syncthreads();
+    HXS(17 + 5 * fb);
   }
+  HXS_WALL(31);
 }
 
 }  // namespace hx
