@@ -9,7 +9,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra $EXTRA_ARGS"
+CMD="python3 $ROOT/bench.py --no-cpu-baseline --no-extra $EXTRA_ARGS"   # default --steps 200 --warmup 50
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"

@@ -66,7 +66,7 @@ for k, cs in counters.items():
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
 
 with open(os.path.join(dst, f"{tag}_pmc_summary.md"), "w") as f:
-    f.write(f"# rocprofv3 summary {tag}\n\nCommand: `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra {bench_args}` "
+    f.write(f"# rocprofv3 summary {tag}\n\nCommand: `python3 bench.py --no-cpu-baseline --no-extra {bench_args}` (default 50 warm-up + 200 timed steps) "
             "(kernel trace and each --pmc group in separate passes; tools/profile_gpu.sh).\n\n")
     for k, d in summary.items():
         f.write(f"## {k}\n\n")
