@@ -18,12 +18,14 @@ from . import _lib, ops, weights
 class HIPPoseModel:
     """CombinedAnglePredictionModel (Model_Builder.py:107-126) on the fused gfx950 kernel."""
 
-    def __init__(self, encoder_sd: dict, head_sds: dict, device="cuda", mode=_lib.MODE_F32):
+    def __init__(self, encoder_sd: dict, head_sds: dict, device="cuda", mode=_lib.MODE_F16X2):
         """mode (int constant or name):
-          _lib.MODE_F32   "f32"    parity mode on the f32 matrix cores (<= 1e-4 deg of the reference; no range limit);
-          _lib.MODE_F16X2 "f16x2"  parity mode on the f16 matrix cores: every f32 operand as two f16 pieces, same
-                                   <= 1e-4 deg bar (measured ~1e-5), ~2.2x the faces/s; |activation| must stay below
-                                   65504 or that face's pose is NaN;
+          _lib.MODE_F16X2 "f16x2"  (default) parity mode on the f16 matrix cores: every f32 operand as two f16 pieces,
+                                   <= 1e-4 deg of the reference (measured ~1e-5), 2.6x the faces/s of the f32 mode and
+                                   0.17 ms instead of 0.30 ms for a 64-face tick; |activation| must stay below 65504 or
+                                   that face's pose is NaN (never silently wrong);
+          _lib.MODE_F32   "f32"    parity mode on the f32 matrix cores (same bar; no range limit; the accumulation is
+                                   the k-ordered fmaf chain, bit-identical to the C oracle);
           _lib.MODE_BF16  "bf16"   throughput mode (bf16 weights/activations, ~0.1 deg from the reference -- never a
                                    parity result)."""
         self.input_size = weights.validate_shapes(encoder_sd, head_sds)
@@ -73,7 +75,7 @@ class HIPPoseModel:
 
 
 def load_model(path_or_dir: str = "models", device=None, encoder_state_dict: dict | None = None,
-               mode=_lib.MODE_F32) -> HIPPoseModel:
+               mode=_lib.MODE_F16X2) -> HIPPoseModel:
     """Build the HIP model from the reference's artefact layout.
 
     path_or_dir: a TorchScript file saved by NLML_HPE_Model_Builder.py (:222-223), or a directory holding
