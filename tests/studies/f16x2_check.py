@@ -1,6 +1,6 @@
-"""Development aid: split-f16 mode vs the f64 oracle + timing (oracle use => tools/, never the product path)."""
+"""Development aid: split-f16 mode vs the f64 oracle + timing (imports the oracle, hence under tests/; never part of the product path)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from nlml_hpe_amd import ops, synth, weights, _lib
 from oracle import encoder_heads as eh, feature_norm as fn

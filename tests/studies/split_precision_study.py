@@ -2,7 +2,7 @@
 
 x = x_hi + x_lo, w = w_hi + w_lo (pieces in f16 or bf16), product = w_hi*x_hi + w_hi*x_lo + w_lo*x_hi
 (+ optional more terms), accumulated in f32.  Weights of a layer may be pre-scaled by a power of two.
-Uses oracle code, so it is a development aid under tools/, not a product path.
+Imports the oracle, hence it lives under tests/; a development aid, never part of the product path.
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
