@@ -128,3 +128,22 @@ def test_synth_generator_is_reproducible():
     assert (a[:, 3:6] == 0).all()
     sd = synth.encoder_state_dict(136, 0)
     assert sd["encoder.0.weight"].shape == (1024, 136) and abs(sd["encoder.0.weight"]).max() <= 1 / np.sqrt(136)
+
+
+def test_mode_names_and_default_are_the_parity_modes():
+    """Host layer: mode constants mirror include/nlml_hpe.h; names map to them; the model default is a PARITY mode."""
+    import inspect
+    import re
+    from nlml_hpe_amd import model as M
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "nlml_hpe.h")).read()
+    consts = {k: int(v) for k, v in re.findall(r"#define\s+NLML_MODE_(\w+)\s+(\d+)", hdr)}
+    assert consts == {"F32": _lib.MODE_F32, "BF16": _lib.MODE_BF16, "F16X2": _lib.MODE_F16X2}
+    assert _lib.mode_from_name("f16x2") == _lib.MODE_F16X2 and _lib.mode_from_name("f32") == 0 and _lib.mode_from_name(1) == 1
+    with pytest.raises(ValueError):
+        _lib.mode_from_name("fp8")
+    with pytest.raises(ValueError):
+        _lib.mode_from_name(9)
+    default = inspect.signature(M.HIPPoseModel.__init__).parameters["mode"].default
+    assert default in (_lib.MODE_F16X2, _lib.MODE_F32), "the default must be one of the two parity modes, never bf16"
+    with pytest.raises(_lib.NlmlError):
+        M.HIPPoseModel(synth.encoder_state_dict(136, 0), weights.load_head_state_dicts("models"), device="cpu")

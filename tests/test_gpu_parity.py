@@ -621,3 +621,21 @@ def test_split_f16_nan_inf_and_f16_overflow_are_loud(head_sds, device):
     ref = EH.forward_numpy(bad[151:152], EH.Params(sd, head_sds), np.float64)
     rel = np.abs(out[151].cpu().numpy() - ref[0]) / np.maximum(1.0, np.abs(ref[0]))
     assert torch.isfinite(out[151]).all() and rel.max() <= 1e-5
+
+
+def test_split_f16_strided_unaligned_input_and_determinism(head_sds, device):
+    """Row stride > F, a start that is not 16-byte aligned (scalar-load path), and bit-identical repeat launches."""
+    F = 136
+    sd = synth.encoder_state_dict(F, seed=0)
+    blob = _blob_hx(sd, head_sds, device)
+    xfull = synth.features(100, 200, seed=4)
+    P = EH.Params(sd, head_sds)
+    for off in (8, 3):                                  # 32-byte offset (vector path) and 12-byte offset (scalar path)
+        xt = torch.from_numpy(xfull).to(device)[:, off:off + F]
+        ref = EH.forward_numpy(xfull[:, off:off + F], P, np.float64)
+        out = ops.encoder_heads_fwd(xt, blob, F)
+        assert np.degrees(np.abs(out.cpu().numpy() - ref).max()) <= POSE_TOL_DEG
+        assert torch.equal(out, ops.encoder_heads_fwd(xt, blob, F))
+    # the vector and the scalar load paths stage the same values: identical bits
+    xa = torch.from_numpy(np.ascontiguousarray(xfull[:, 3:3 + F])).to(device)
+    assert torch.equal(ops.encoder_heads_fwd(xa, blob, F), ops.encoder_heads_fwd(torch.from_numpy(xfull).to(device)[:, 3:3 + F], blob, F))
