@@ -57,6 +57,9 @@ def parse():
                     help="fused: raw landmarks in (K1+K2 in one launch); features: normalised features in (K2)")
     ap.add_argument("--mode", choices=["f16x2", "f32"], default="f16x2",
                     help="parity kernel: f16x2 = split-f16 operands on the f16 matrix cores; f32 = f32 matrix cores")
+    ap.add_argument("--settle-ms", type=float, default=250.0,
+                    help="that many untimed steps (~1 ms each) BEFORE the W warm-up steps, so that short K/W also measure "
+                         "the sustained (power-limited) rate; reported in the JSON as config.settle_ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -139,6 +142,9 @@ def main():
         if gatherer is not None:
             gatherer.drain()
 
+    if args.settle_ms > 0:                      # clock/power settling, untimed (see --settle-ms).  A FIXED number of steps
+        run_steps(int(args.settle_ms))          # (~1 ms each), identical on every rank: the steps contain a collective
+        torch.cuda.synchronize()
     run_steps(args.warmup)
     torch.cuda.synchronize()
     barrier()
@@ -188,7 +194,7 @@ def main():
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: gloo, shared devices -- not a measurement)",
             "config": {"workload": f"landmarks->pose, batch {B}/GPU, F=1404 (468x3 landmarks), encoder+3 heads fused HIP forward, "
                                    f"{what}, path={args.path}",
-                       "faces_per_gpu": B, "F": F, "path": args.path, "mode": args.mode,
+                       "faces_per_gpu": B, "F": F, "path": args.path, "mode": args.mode, "settle_ms": args.settle_ms,
                        "seeds": {"encoder": 0, "landmarks": "1+rank"},
                        "collective": "all_gather f32[B,3] per step" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
