@@ -50,9 +50,9 @@ struct TuckerShared {
 // par(e, k): parameter k (w_y, w_p, w_r, u_id[5]) of evaluation e.  cp4: this thread's cosine row
 // (threads < 144 only).  Leaves acc[mb][r] = x_hat of evaluation (lane>>4) + 4r at column
 // 16*(11*wave + mb) + (lane&15).
+// Coefficient phase: f-vectors and c[q][e] of all 16 evaluations into LDS (two barriers inside).
 template <typename ParT>
-__device__ __forceinline__ void tucker_xhat(TuckerShared& sh, const float* __restrict__ Wm, const ParT& par,
-                                            const double (&cp4)[4], int tid, f64x4 (&acc)[MBW]) {
+__device__ __forceinline__ void tucker_coef(TuckerShared& sh, const ParT& par, const double (&cp4)[4], int tid) {
   if (tid < EV * 9) {
     const int e = tid / 9, a = (tid % 9) / 3;
     const double v = cp4[0] * cos(cp4[1] * par(e, a) + cp4[2]) + cp4[3];
@@ -65,7 +65,11 @@ __device__ __forceinline__ void tucker_xhat(TuckerShared& sh, const float* __res
     sh.coef[q][e] = q < TQ ? ((par(e, 3 + ui) * sh.fvec[e][0][j]) * sh.fvec[e][1][k]) * sh.fvec[e][2][l] : 0.0;
   }
   __syncthreads();
+}
 
+// Matrix-core phase (after tucker_coef): leaves acc[mb][r] = x_hat of evaluation (lane>>4) + 4r at column
+// 16*(11*wave + mb) + (lane&15).
+__device__ __forceinline__ void tucker_mfma(TuckerShared& sh, const float* __restrict__ Wm, int tid, f64x4 (&acc)[MBW]) {
   const int lane = tid & 63, wv = tid >> 6;
   const int kq = lane >> 4, col = lane & 15;
   // column of this lane in block mb: 16*(11*wv + mb) + col.  One base pointer + immediate offsets (64 B per
@@ -108,6 +112,86 @@ __device__ __forceinline__ void tucker_xhat(TuckerShared& sh, const float* __res
   }
 #pragma unroll
   for (int r = 0; r < TAIL; ++r) step(GROUPS * TRING + r, r, false);
+}
+
+template <typename ParT>
+__device__ __forceinline__ void tucker_xhat(TuckerShared& sh, const float* __restrict__ Wm, const ParT& par,
+                                            const double (&cp4)[4], int tid, f64x4 (&acc)[MBW]) {
+  tucker_coef(sh, par, cp4, tid);
+  tucker_mfma(sh, Wm, tid, acc);
+}
+
+// NE (1..4) evaluations on the vector ALUs in ONE pass over Wm, bit-identical to what the matrix-core path leaves in
+// sh.red[.][e] for them (after tucker_coef; the caller's barrier makes red visible).  Used by the Powell kernel when
+// only a few of a workgroup's 16 machines are still running: the MFMA pass costs the same for 1 live evaluation as
+// for 16, and either way a round cannot be shorter than streaming Wm (758 KB) through one CU (~11 us).
+//   x_hat[m]  the same q-ascending fma chain from +0.0 that one MFMA output accumulates (the padded q = 135
+//             step adds 0 * w and is skipped);
+//   residual  lane (wave w, column group c = lane & 15) owns the columns 16*(11w + mb) + c, mb = 0..10: the four
+//             16-lane quarters of the wave split the 11 blocks (quarter j takes mb = j, j+4, j+8), the differences
+//             are gathered back by shuffles and squared-and-summed in ascending mb order, then the same xor butterfly.
+template <int NE>
+__device__ __attribute__((noinline)) void tucker_few(TuckerShared& sh, const float* __restrict__ Wm,
+                                           const float* const (&xe)[NE], const int (&ev)[NE], int tid) {
+  const int lane = tid & 63, wv = tid >> 6, col = lane & 15, j = lane >> 4;
+  int mc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int mb = j + 4 * i;                                   // quarter 3 has no third block: it recomputes mb 7
+    const int m = 16 * (MBW * wv + (mb < MBW ? mb : MBW - 4)) + col;
+    mc[i] = m < TM ? m : TM - 1;
+  }
+  double acc[3][NE];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int n = 0; n < NE; ++n) acc[i][n] = 0.0;
+  // Wm streams through registers fifteen rows at a time (45 dwords per lane in flight, 92 KB per CU)
+  constexpr int QB = 15;
+  static_assert(TQ % QB == 0, "135 = 9 x 15");
+  float w[2][QB][3];
+#pragma unroll
+  for (int qq = 0; qq < QB; ++qq)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w[0][qq][i] = Wm[(size_t)qq * TM + mc[i]];
+#pragma unroll 1
+  for (int qb = 0; qb < TQ / QB; qb += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int q0 = (qb + half) * QB;
+      if (q0 < TQ) {
+        const int qn = q0 + QB < TQ ? q0 + QB : q0;             // next block (the last one re-reads itself)
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) w[half ^ 1][qq][i] = Wm[(size_t)(qn + qq) * TM + mc[i]];
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq)
+#pragma unroll
+          for (int n = 0; n < NE; ++n) {
+            const double c = sh.coef[q0 + qq][ev[n]];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i][n] = fma(c, (double)w[half][qq][i], acc[i][n]);
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NE; ++n) {
+    double d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = (double)xe[n][mc[i]] - acc[i][n];
+    double s = 0.0;
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb) {
+      const double dv = __shfl(d[mb >> 2], ((mb & 3) << 4) | col, 64);
+      const bool live = 16 * (MBW * wv + mb) + col < TM;
+      s = live ? fma(dv, dv, s) : s;
+    }
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) sh.red[wv][ev[n]] = s;
+  }
 }
 
 // Residual norms of the 16 evaluations.  xv[mb][r] = x of evaluation (lane>>4) + 4r at this lane's column of

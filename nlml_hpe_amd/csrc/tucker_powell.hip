@@ -11,7 +11,8 @@
 //
 // Faces are independent, so there is no grid-level synchronisation: a workgroup runs as many
 // rounds as its slowest face needs (1.4k-7k).  The machine state lives in LDS.  Every round costs one Wm pass (758 KB from L2) per 8
-// faces: ~383.7 kFLOP (f64) per face-evaluation, the same roofline as K3.
+// faces: ~383.7 kFLOP (f64) per face-evaluation, the same roofline as K3.  Rounds with at most PW_FEW live machines take
+// the vector-ALU pass tucker_few (tucker_common.h): same bits, one Wm stream, no 16-wide MFMA work for dead machines.
 #include <hip/hip_runtime.h>
 
 #include "abi_internal.h"
@@ -23,6 +24,8 @@ namespace nlml {
 // The state machine is a large switch; inlined into the kernel it inflates the register demand of the
 // whole function (spills in the MFMA loop).  As a real call its registers are its own.
 __device__ __attribute__((noinline)) bool powell_step_call(PowellState* s, double f) { return powell_step(*s, f); }
+
+constexpr int PW_FEW = 4;   // at most this many live machines: evaluate them on the vector ALUs (tucker_few)
 
 struct LdsPar {
   const double (*p)[PW_N];
@@ -76,22 +79,45 @@ __global__ __launch_bounds__(TNT, 2) void tucker_powell_kernel(
 
   const LdsPar lp{par};
   for (int round = 0; round < PW_N * 1000 + 16; ++round) {
-    int any = 0;
+    int live_mask = 0;
 #pragma unroll
-    for (int e = 0; e < EV; ++e) any |= need[e];
-    if (!any) break;
+    for (int e = 0; e < EV; ++e) live_mask |= need[e] << e;
+    if (!live_mask) break;
 
-    f64x4 acc[MBW];
-    tucker_xhat(sh, Wm, lp, cp4, tid, acc);
-    float xv[MBW][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int mb = 0; mb < MBW; ++mb) {
-        const int m = 16 * (MBW * wv + mb) + col;
-        xv[mb][r] = xrow[r][m < TM ? m : TM - 1];
+    tucker_coef(sh, lp, cp4, tid);
+    if (__popc(live_mask) <= PW_FEW) {
+      // the tail of a workgroup's run: one to a few machines left (a face that needs 6,000 evaluations next to fifteen
+      // that needed 1,500).  Their evaluations share ONE pass over Wm on the vector ALUs, bit-identical to the MFMA pass.
+      int ev[PW_FEW];
+      const float* xe[PW_FEW];
+      int ne = 0;
+      for (int mleft = live_mask; mleft; mleft &= mleft - 1) {
+        const int e = __ffs(mleft) - 1;
+        int64_t n = e0 + e;
+        n = n < N ? n : N - 1;
+        ev[ne] = e;
+        xe[ne++] = x + n * ldx;
       }
-    tucker_residual(sh, xv, acc, tid);
+      switch (ne) {   // the count is a compile-time parameter of the pass: its accumulators live in registers
+        case 1: { const int e1[1] = {ev[0]}; const float* const x1[1] = {xe[0]}; tucker_few<1>(sh, Wm, x1, e1, tid); break; }
+        case 2: { const int e2[2] = {ev[0], ev[1]}; const float* const x2[2] = {xe[0], xe[1]}; tucker_few<2>(sh, Wm, x2, e2, tid); break; }
+        case 3: { const int e3[3] = {ev[0], ev[1], ev[2]}; const float* const x3[3] = {xe[0], xe[1], xe[2]}; tucker_few<3>(sh, Wm, x3, e3, tid); break; }
+        default: { const int e4[4] = {ev[0], ev[1], ev[2], ev[3]}; const float* const x4[4] = {xe[0], xe[1], xe[2], xe[3]}; tucker_few<4>(sh, Wm, x4, e4, tid); break; }
+      }
+      __syncthreads();
+    } else {
+      f64x4 acc[MBW];
+      tucker_mfma(sh, Wm, tid, acc);
+      float xv[MBW][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) {
+          const int m = 16 * (MBW * wv + mb) + col;
+          xv[mb][r] = xrow[r][m < TM ? m : TM - 1];
+        }
+      tucker_residual(sh, xv, acc, tid);
+    }
 
     if (me >= 0 && need[me]) {   // resume the state machines with their objective values
       const bool nd = powell_step_call(&st[me], tucker_err(sh, me));
