@@ -132,7 +132,7 @@ __device__ __forceinline__ void tucker_xhat(TuckerShared& sh, const float* __res
 //             are gathered back by shuffles and squared-and-summed in ascending mb order, then the same xor butterfly.
 template <int NE>
 __device__ __attribute__((noinline)) void tucker_few(TuckerShared& sh, const float* __restrict__ Wm,
-                                           const float* const (&xe)[NE], const int (&ev)[NE], int tid) {
+                                           const float* (&xe)[NE], const int (&ev)[NE], int tid) {
   const int lane = tid & 63, wv = tid >> 6, col = lane & 15, j = lane >> 4;
   int mc[3];
 #pragma unroll

@@ -25,7 +25,9 @@ namespace nlml {
 // whole function (spills in the MFMA loop).  As a real call its registers are its own.
 __device__ __attribute__((noinline)) bool powell_step_call(PowellState* s, double f) { return powell_step(*s, f); }
 
-constexpr int PW_FEW = 4;   // at most this many live machines: evaluate them on the vector ALUs (tucker_few)
+// at most this many live machines: evaluate them on the vector ALUs (tucker_few), ~19 us a round against ~36 us for an
+// MFMA round; measured on BASELINE config 3: 4 -> 0.153 s, 8 -> 0.163 s, MFMA only -> 0.242 s
+constexpr int PW_FEW = 4;
 
 struct LdsPar {
   const double (*p)[PW_N];
@@ -98,12 +100,20 @@ __global__ __launch_bounds__(TNT, 2) void tucker_powell_kernel(
         ev[ne] = e;
         xe[ne++] = x + n * ldx;
       }
-      switch (ne) {   // the count is a compile-time parameter of the pass: its accumulators live in registers
-        case 1: { const int e1[1] = {ev[0]}; const float* const x1[1] = {xe[0]}; tucker_few<1>(sh, Wm, x1, e1, tid); break; }
-        case 2: { const int e2[2] = {ev[0], ev[1]}; const float* const x2[2] = {xe[0], xe[1]}; tucker_few<2>(sh, Wm, x2, e2, tid); break; }
-        case 3: { const int e3[3] = {ev[0], ev[1], ev[2]}; const float* const x3[3] = {xe[0], xe[1], xe[2]}; tucker_few<3>(sh, Wm, x3, e3, tid); break; }
-        default: { const int e4[4] = {ev[0], ev[1], ev[2], ev[3]}; const float* const x4[4] = {xe[0], xe[1], xe[2], xe[3]}; tucker_few<4>(sh, Wm, x4, e4, tid); break; }
+      // the count is a compile-time parameter of the pass: its accumulators live in registers
+#define NLML_FEW_CASE(K)                                                  \
+  case K: {                                                               \
+    int ek[K];                                                            \
+    const float* xk[K];                                                   \
+    for (int i = 0; i < K; ++i) { ek[i] = ev[i]; xk[i] = xe[i]; }         \
+    tucker_few<K>(sh, Wm, xk, ek, tid);                                   \
+    break;                                                                \
+  }
+      switch (ne) {
+        NLML_FEW_CASE(1) NLML_FEW_CASE(2) NLML_FEW_CASE(3) NLML_FEW_CASE(4)
+        default: break;   // unreachable: ne <= PW_FEW
       }
+#undef NLML_FEW_CASE
       __syncthreads();
     } else {
       f64x4 acc[MBW];
