@@ -639,3 +639,19 @@ def test_split_f16_strided_unaligned_input_and_determinism(head_sds, device):
     # the vector and the scalar load paths stage the same values: identical bits
     xa = torch.from_numpy(np.ascontiguousarray(xfull[:, 3:3 + F])).to(device)
     assert torch.equal(ops.encoder_heads_fwd(xa, blob, F), ops.encoder_heads_fwd(torch.from_numpy(xfull).to(device)[:, 3:3 + F], blob, F))
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "f32"])
+def test_repeat_launches_are_bit_identical_under_load(mode, head_sds, device):
+    """200 back-to-back launches (all 256 CUs busy, clocks and power moving) of the fused path on the same 16,384 faces
+    return the same bits every time: the LDS slab rotation, the two-pass layer 0 and the prefetch rings have no
+    timing-dependent hazard."""
+    from nlml_hpe_amd import _lib
+    sd = synth.encoder_state_dict(1404, seed=0)
+    blob = torch.from_numpy(weights.pack_blob(sd, head_sds, _lib.mode_from_name(mode))).to(device)
+    raw = torch.from_numpy(synth.raw_landmarks(16384, seed=31)).to(device)
+    first = ops.landmarks_to_pose(raw, blob, True).clone()
+    bad = torch.zeros((), dtype=torch.int64, device=device)
+    for _ in range(200):
+        bad += (ops.landmarks_to_pose(raw, blob, True) != first).sum()
+    assert int(bad.item()) == 0
