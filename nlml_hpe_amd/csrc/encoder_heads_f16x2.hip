@@ -3,7 +3,7 @@
 // Same network, stages and jobs as the f32 parity kernel (encoder_heads.hip; reference:
 // NLML_HPE_Model_Builder.py:33-53,76-92,115-126) and the same <=1e-4 degree bar, but the contraction runs on
 // the f16 matrix cores: every f32 operand v is carried as two f16 pieces, v = hi + lo, hi = f16(v),
-// lo = f16(v - hi) (22 significand bits), and a product is evaluated as
+// lo = f16(v - hi) (v - hi is exact in f32 and lo keeps 11 bits of it: >= 22 significand bits), and a product is evaluated as
 //
 //     w*x  ~  w_hi*x_hi + w_hi*x_lo + w_lo*x_hi          (three v_mfma_f32_32x32x16_f16, f32 accumulate)
 //
