@@ -173,6 +173,23 @@ int nlml_video_post(const float* pose_rad, const float* raw, const uint8_t* vali
                     double frame_w, double frame_h, double alpha, double max_jump, double size,
                     double* state, double* smoothed, double* centre, double* endpoints, void* stream);
 
+/* Artefact producers that are pure tensor algebra.
+ *
+ * nlml_cosine_table replaces the two nested loops over cosine() that build the heads' training inputs
+ * (NLML_HPE_MLPHeadsTrainer.py:71-73,179-205): out[i][j] = a_j*cos(b_j*w_i + c_j) + d_j in f64.
+ *   angles_rad f32[n]   np.radians(np.arange(min, max, interval).astype(np.float32)) (:179-181)
+ *   cos_params f64[R,4] rows (a,b,c,d) = optimized_{yaw,pitch,roll} of outputs/features/Trained_data.npz
+ *   out        f64[n,R]
+ *
+ * nlml_mode5_product replaces W = tl.tensordot(core, transpose(feature_matrix), axes=(4,0)) (TD_main.py:232-238):
+ * W[q][m] = sum_r core[q][r] * U_feat[m][r], an r-ascending f32 fma chain per output.
+ *   core   f32[Q,R5]  the Tucker core with its four leading modes flattened (Q = 135 for the shipped model)
+ *   U_feat f32[M,R5]  mode-5 factor matrix (M = 1404 features)
+ *   W      f32[Q,M]
+ */
+int nlml_cosine_table(const float* angles_rad, int64_t n, const double* cos_params, int R, double* out, void* stream);
+int nlml_mode5_product(const float* core, const float* U_feat, int Q, int R5, int M, float* W, void* stream);
+
 /* Host-side stepping of the same Powell state machine (no GPU involved): the caller evaluates
  * the objective.  Used to check the restated control flow against scipy on the CPU.
  *   h_state: caller-allocated buffer of nlml_powell_state_bytes() bytes.

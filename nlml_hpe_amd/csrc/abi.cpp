@@ -108,6 +108,18 @@ int nlml_video_post(const float* pose_rad, const float* raw, const uint8_t* vali
                            endpoints, stream);
 }
 
+int nlml_cosine_table(const float* angles_rad, int64_t n, const double* cos_params, int R, double* out, void* stream) {
+  if (n < 0 || R < 0) return fail(NLML_E_BADARG, "cosine_table: negative size");
+  if (n > 0 && R > 0 && (!angles_rad || !cos_params || !out)) return fail(NLML_E_BADARG, "cosine_table: null buffer");
+  return launch_cosine_table(angles_rad, n, cos_params, R, out, stream);
+}
+
+int nlml_mode5_product(const float* core, const float* U_feat, int Q, int R5, int M, float* W, void* stream) {
+  if (Q < 0 || R5 < 0 || M < 0) return fail(NLML_E_BADARG, "mode5_product: negative size");
+  if (Q > 0 && M > 0 && (!W || (R5 > 0 && (!core || !U_feat)))) return fail(NLML_E_BADARG, "mode5_product: null buffer");
+  return launch_mode5_product(core, U_feat, Q, R5, M, W, stream);
+}
+
 // ---- host-side stepping of the Powell state machine (powell.h) --------------------------------
 size_t nlml_powell_state_bytes(void) { return sizeof(PowellState); }
 

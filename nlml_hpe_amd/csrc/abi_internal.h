@@ -26,6 +26,9 @@ int launch_encoder_heads_bf16(const float* x, int64_t ldx, const float* raw, int
 int launch_encoder_heads_f16x2(const float* x, int64_t ldx, const float* raw, int normalize,
                                int64_t B, int F, const void* blob, float* out, float* latent,
                                uint8_t* valid, void* stream);
+// artefacts.hip
+int launch_cosine_table(const float* angles, int64_t n, const double* cos_params, int R, double* out, void* stream);
+int launch_mode5_product(const float* core, const float* U, int Q, int R5, int M, float* W, void* stream);
 // normalize_ipd.hip
 int launch_normalize_ipd(const float* raw, int64_t B, int normalize, float* out, uint8_t* valid,
                          void* stream);

@@ -225,3 +225,35 @@ def tucker_powell(Wm: torch.Tensor, x: torch.Tensor, cos_params: torch.Tensor, x
                                              nfev.data_ptr(), nit.data_ptr(), status.data_ptr(), _stream_ptr()),
                "nlml_tucker_powell")
     return {"x": res, "fun": fun, "nfev": nfev, "nit": nit, "status": status}
+
+
+def cosine_table(angles_rad: torch.Tensor, cos_params: torch.Tensor) -> torch.Tensor:
+    """U[i,j] = a_j*cos(b_j*w_i + c_j) + d_j in f64 (NLML_HPE_MLPHeadsTrainer.py:71-73,179-205).
+
+    angles_rad f32[n] (radians), cos_params f64[R,4] rows (a,b,c,d) -> f64[n,R]."""
+    _need_cuda(angles_rad, "angles_rad", torch.float32)
+    _need_cuda(cos_params, "cos_params", torch.float64)
+    if angles_rad.dim() != 1 or cos_params.dim() != 2 or cos_params.shape[1] != 4:
+        raise ValueError(f"expected angles [n] and cos_params [R,4], got {tuple(angles_rad.shape)}, {tuple(cos_params.shape)}")
+    angles_rad, cos_params = angles_rad.contiguous(), cos_params.contiguous()
+    n, R = angles_rad.shape[0], cos_params.shape[0]
+    out = torch.empty((n, R), dtype=torch.float64, device=angles_rad.device)
+    _lib.check(_lib.lib().nlml_cosine_table(angles_rad.data_ptr(), n, cos_params.data_ptr(), R, out.data_ptr(), _stream_ptr()),
+               "nlml_cosine_table")
+    return out
+
+
+def mode5_product(core: torch.Tensor, U_feat: torch.Tensor) -> torch.Tensor:
+    """W = core x_5 U_feat (TD_main.py:232-238): core f32[..., R5], U_feat f32[M, R5] -> W f32[..., M]."""
+    _need_cuda(core, "core", torch.float32)
+    _need_cuda(U_feat, "U_feat", torch.float32)
+    if U_feat.dim() != 2 or core.dim() < 1 or core.shape[-1] != U_feat.shape[1]:
+        raise ValueError(f"core [..., R5] and U_feat [M, R5] disagree: {tuple(core.shape)}, {tuple(U_feat.shape)}")
+    lead = tuple(core.shape[:-1])
+    c2 = core.contiguous().reshape(-1, core.shape[-1])
+    U_feat = U_feat.contiguous()
+    Q, R5, M = c2.shape[0], c2.shape[1], U_feat.shape[0]
+    W = torch.empty((Q, M), dtype=torch.float32, device=core.device)
+    _lib.check(_lib.lib().nlml_mode5_product(c2.data_ptr(), U_feat.data_ptr(), Q, R5, M, W.data_ptr(), _stream_ptr()),
+               "nlml_mode5_product")
+    return W.reshape(lead + (M,))

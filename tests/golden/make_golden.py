@@ -14,6 +14,7 @@ What is imported from /root/reference and called (file:line of the callee):
   FX5  TD_Tester.py:162                 Test (scipy Powell)
   FX6  NLML_HPE_Test.py:62,95           compute_maev, compute_errors
   FX7  generatePose_on_video.py:73,128  visualize_axes_on_face, process_video (EMA loop)
+  FX8  NLML_HPE_MLPHeadsTrainer.py:71   cosine (called in the loops of :179-205 on the config_MlpHeads.yaml grids)
 
 cv2 / mediapipe are not installed; empty stub modules satisfy the imports, and
 for FX7 the handful of cv2 / FaceMesh entry points process_video touches are
@@ -306,9 +307,32 @@ def fx7_video_math():
     print("FX7 frames recorded", len(rec), "of", T)
 
 
+def fx8_cosine_table():
+    """The heads' training table: the reference's cosine() in the loops of NLML_HPE_MLPHeadsTrainer.py:179-205, on the
+    angle grids of the reference's configs/config_MlpHeads.yaml and the shipped optimised cosine rows."""
+    import yaml
+    import NLML_HPE_MLPHeadsTrainer as HT
+    cfg = yaml.safe_load(open(os.path.join(REF, "configs", "config_MlpHeads.yaml")))
+    td = np.load(os.path.join(REPO, "outputs", "features", "Trained_data.npz"))
+    out = {}
+    for name in ("yaw", "pitch", "roll"):
+        b = cfg[f"{name}_bins"]
+        ang = np.radians(np.arange(b["min_bin"], b["max_bin"], b["interval"]).astype(np.float32))      # :179-181
+        opt = td[f"optimized_{name}"]
+        U = np.zeros((len(ang), opt.shape[0]))                                                        # :183-185
+        for i, w in enumerate(ang):                                                                   # :189-205
+            for j, row in enumerate(opt):
+                a, b_, c, d = row
+                U[i][j] = HT.cosine(w, a, b_, c, d)
+        out[f"angles_{name}"] = ang
+        out[f"U_{name}"] = U
+    np.savez_compressed(os.path.join(HERE, "fx8_cosine_table.npz"), **out)
+    print("FX8", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7"]
+    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8"]
     table = {"1": fx1_normalise, "2": fx2_heads, "3": fx3_encoder_heads, "4": fx4_td_objective,
-             "5": fx5_td_end_to_end, "6": fx6_metrics, "7": fx7_video_math}
+             "5": fx5_td_end_to_end, "6": fx6_metrics, "7": fx7_video_math, "8": fx8_cosine_table}
     for w in which:
         table[w]()

@@ -655,3 +655,47 @@ def test_repeat_launches_are_bit_identical_under_load(mode, head_sds, device):
     for _ in range(200):
         bad += (ops.landmarks_to_pose(raw, blob, True) != first).sum()
     assert int(bad.item()) == 0
+
+
+# ---- artefact producers ---------------------------------------------------------------------
+def test_fx8_cosine_table_on_device(tucker_art, golden_dir, repo_root, device):
+    """The heads' training table against FX8 (the reference's own cosine() on its config grids): f64; the device's cos
+    and numpy's may differ in the last place, which a*cos()+d turns into an ulp of |a|+|d| (yaw row 3: -9.56*cos+9.25),
+    so the tolerance is 4 eps * max_j(|a_j| + |d_j|) absolute."""
+    import yaml
+    from nlml_hpe_amd import artefacts
+    g = np.load(os.path.join(golden_dir, "fx8_cosine_table.npz"))
+    cfg = yaml.safe_load(open(os.path.join(repo_root, "configs", "config_MlpHeads.yaml")))
+    opt = {n: tucker_art[f"optimized_{n}"] for n in ("yaw", "pitch", "roll")}
+    tab = artefacts.heads_training_table(cfg, opt, device=device)
+    for name in ("yaw", "pitch", "roll"):
+        U, ang = tab[name]
+        assert np.array_equal(ang, g[f"angles_{name}"])
+        ref = g[f"U_{name}"]
+        err = np.abs(U.cpu().numpy() - ref).max()
+        _report(f"fx8_cosine_table_{name}", max_abs=err)
+        scale = float((np.abs(opt[name][:, 0]) + np.abs(opt[name][:, 3])).max())
+        assert err <= 4 * np.finfo(np.float64).eps * scale, (err, scale)
+
+
+def test_mode5_product_on_device(tucker_art, device):
+    """W = core x_5 U_feat: bit-exact against the r-ascending f32 fma chain on a small case; at the shipped shape
+    ([135,1404] x [1404,1404], orthonormal synthetic U_feat) within f32 accumulation error of the f64 product, and the
+    product undoes itself (W x_5 U_feat^T == core).  U_feat is not among the shipped artefacts (parity unpinned)."""
+    from oracle import artefacts as AR
+    rng = np.random.default_rng(5)
+    core_s = rng.standard_normal((2, 3, 3, 3, 70)).astype(np.float32)
+    U_s = rng.standard_normal((45, 70)).astype(np.float32)
+    got = ops.mode5_product(torch.from_numpy(core_s).to(device), torch.from_numpy(U_s).to(device)).cpu().numpy()
+    assert got.shape == (2, 3, 3, 3, 45)
+    assert np.array_equal(got.reshape(-1, 45), AR.mode5_product_chain_f32(core_s.reshape(-1, 70), U_s))
+    core = tucker_art["CoreTensor"].astype(np.float32)                     # [5,3,3,3,1404]
+    Uf, _ = np.linalg.qr(rng.standard_normal((1404, 1404)))
+    Uf = Uf.astype(np.float32)
+    W = ops.mode5_product(torch.from_numpy(core).to(device), torch.from_numpy(Uf).to(device))
+    W64 = AR.mode5_product(core, Uf)
+    rel = np.abs(W.cpu().numpy() - W64).max() / np.abs(W64).max()
+    back = ops.mode5_product(W, torch.from_numpy(np.ascontiguousarray(Uf.T)).to(device)).cpu().numpy()
+    rel_back = np.abs(back - core).max() / np.abs(core).max()
+    _report("mode5_product", rel_vs_f64=rel, roundtrip_rel=rel_back)
+    assert rel <= 2e-5 and rel_back <= 1e-4

@@ -124,3 +124,30 @@ def test_fx7_video_math(golden_dir):
         prev = (tdx, tdy)
     jumps = [i for i in range(1, len(frames)) if frames[i]["centre"] == frames[i - 1]["centre"]]
     assert jumps, "fixture must exercise the >100 px jump gate"
+
+
+def test_fx8_cosine_table_oracle(golden_dir):
+    """FX8: the heads' training table built by the reference's own cosine() (NLML_HPE_MLPHeadsTrainer.py:71-73,179-205)."""
+    from oracle import artefacts as AR
+    g = np.load(os.path.join(golden_dir, "fx8_cosine_table.npz"))
+    td = np.load(os.path.join(os.path.dirname(os.path.dirname(golden_dir)), "outputs", "features", "Trained_data.npz"))
+    for name, n in (("yaw", 1001), ("pitch", 801), ("roll", 601)):
+        ang = g[f"angles_{name}"]
+        assert ang.dtype == np.float32 and ang.shape == (n,)
+        U = AR.cosine_table(ang, td[f"optimized_{name}"])
+        assert np.array_equal(U, g[f"U_{name}"])
+
+
+def test_mode5_product_oracle_forms_agree():
+    """The n-mode product restated two ways (tensordot in f64; the kernel's f32 fma chain) on a small case, and the
+    defining property: with orthonormal U_feat, contracting W back with U_feat recovers the core."""
+    from oracle import artefacts as AR
+    rng = np.random.default_rng(5)
+    core = rng.standard_normal((2, 3, 3, 3, 24)).astype(np.float32)
+    Uf, _ = np.linalg.qr(rng.standard_normal((40, 24)))
+    Uf = Uf.astype(np.float32)                                  # [M=40, R5=24], orthonormal columns
+    W64 = AR.mode5_product(core, Uf)
+    chain = AR.mode5_product_chain_f32(core.reshape(-1, 24), Uf).reshape(2, 3, 3, 3, 40)
+    assert np.abs(chain - W64).max() <= 5e-6 * np.abs(W64).max()
+    back = np.tensordot(W64, Uf.astype(np.float64), axes=(4, 0))
+    assert np.abs(back - core).max() <= 1e-5
