@@ -29,6 +29,8 @@ def NLML_HPE_Tester(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--device", default=None)
     ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--mode", choices=["f16x2", "f32", "bf16"], default=None,
+                    help="kernel mode (default: NLML_HPE_MODE or f16x2; both f16x2 and f32 meet the 1e-4 deg bar)")
     args = ap.parse_args(argv)
     warnings.filterwarnings("default")
 
@@ -51,7 +53,7 @@ def NLML_HPE_Tester(argv=None):
     hi = np.array([bins["yaw_bins"]["max_bin"], bins["pitch_bins"]["max_bin"], bins["roll_bins"]["max_bin"]], dtype=np.float64)
     intervals = [[tuple(x) for x in cfg[k]] for k in ("yaw_intervals", "pitch_intervals", "roll_intervals")]
 
-    model = resolve_model(device, input_size=bins["input_size"])
+    model = resolve_model(device, input_size=bins["input_size"], mode=args.mode)
     model.eval()
 
     if cfg["val_set"] == "landmarks_npz":

@@ -71,10 +71,12 @@ if __name__ == "__main__":
     parser.add_argument("--save_output", type=lambda s: str(s).lower() in ("1", "true", "yes", "tr"), required=True)
     parser.add_argument("--output_path", type=str)
     parser.add_argument("--device", default="cuda:0")
+    parser.add_argument("--mode", choices=["f16x2", "f32", "bf16"], default=None,
+                        help="kernel mode (default: NLML_HPE_MODE or f16x2)")
     args = parser.parse_args()
     dev = torch.device(args.device)
     torch.cuda.set_device(dev)
     # the reference loads models/combined_model_scripted_prev.pth here (:289)
-    mdl = resolve_model(dev, scripted_name="models/combined_model_scripted_prev.pth")
+    mdl = resolve_model(dev, scripted_name="models/combined_model_scripted_prev.pth", mode=args.mode)
     mdl.eval()
     process_video(args.source, args.output_path, mdl, args.save_output, dev)
