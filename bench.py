@@ -307,6 +307,12 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
                                      "max_abs_deg_vs_f32_mode": float(torch.rad2deg(d.max())),
                                      "mean_abs_deg_vs_f32_mode": float(torch.rad2deg(d.mean())),
                                      "note": "throughput mode; fails the 1e-4 deg parity bar by design (SURVEY D3)"}
+    # BASELINE config 4 per GPU: an AFLW2000-shaped stream, 2,000 faces per step (32 tiles: 1/8 of the CUs busy, so the
+    # rate is set by one tile's latency; the all-gather of config 4 exists only at N > 1: --batch 2000 --gpus N)
+    r2k = raw[:2000].contiguous()
+    for name, b in (("f16x2", blob_hx), ("f32", blob)):
+        ms = time_kernel(lambda: ops.landmarks_to_pose(r2k, b, True), 200, warm=50)
+        ex[f"config4_2000_faces_step_{name}"] = {"ms_per_step": ms, "faces_per_sec": 2000 / ms * 1e3}
     ms = time_kernel(lambda: ops.normalize_ipd(raw, True), 20)
     ex["k1_normalize"] = {"faces_per_sec": B / ms * 1e3, "gbs": B * BYTES_PER_FACE_K1 / ms / 1e6,
                           "hbm_frac": B * BYTES_PER_FACE_K1 / ms / 1e6 / PEAK_HBM_GBS}
