@@ -3,8 +3,9 @@
 Same names and argument meaning as /root/reference/TD_Tester.py for the functions on the hot path:
   func(w, params)                                  :25-28
   objective(params, W, x, params_y, params_p, params_r)   :31-58   -> float (one evaluation, K3 kernel)
+  compute_gradient(params, W, x, params_y, params_p, params_r) :60-102 -> f64[8] (the jac= the reference hands to Powell)
   Test(W, x, u_id_shape, Py, Pp, Pr, u_id, f_y, f_p, f_r) :162-291 -> (yaw deg, pitch deg, roll deg, u_id)
-plus the batched forms this build adds: objective_batch, Test_batch.
+plus the batched forms this build adds: objective_batch, compute_gradient_batch, Test_batch.
 The module-level debug lists of the reference (:18-22, appended on every call, unbounded) are not kept.
 """
 from __future__ import annotations
@@ -71,6 +72,49 @@ def objective_batch(params, W, X, params_y, params_p, params_r, x_index=None, re
 def objective(params, W, x, params_y, params_p, params_r):
     """One evaluation, same signature as the reference (:31); x may be a torch tensor or an array."""
     return float(objective_batch(np.asarray(params, dtype=np.float64)[None], W, x, params_y, params_p, params_r)[0])
+
+
+def compute_gradient_batch(params, W, X, params_y, params_p, params_r):
+    """Analytic gradient of the objective (:60-102) for N evaluations at once, on the device in f64.
+
+    With c = u (x) f_y (x) f_p (x) f_r, r = x - c^T Wm (x_hat from the K3 kernel) and g = Wm r, the reference's four
+    gradient einsums are dot products with g:  d/dw_a = -<dc/dw_a, g>, dc/dw_y = u (x) f_y' (x) f_p (x) f_r with
+    f' = f32(-a b sin(b w + c)) (:80-95).  The identity-mode term is reproduced as the reference writes it (:96): its inner
+    einsum also sums over i, so grad_u[i] = -sum_m S[i,m] r[m] v[m], v = (1 (x) f_y (x) f_p (x) f_r)^T Wm, S[i] = sum_jkl W[i,j,k,l].
+    The three small GEMMs are library f64 matmuls (rocBLAS through torch).  -> f64[N,8] (numpy)."""
+    dev = _dev()
+    P = torch.from_numpy(np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 8)).to(dev)
+    cp = _cos(params_y, params_p, params_r)                                   # [3 angles, 3 rows, (a,b,c,d)]
+    Wm = _wm(W)
+    Xd = _x(X)
+    _, xh = ops.tucker_objective(Wm, Xd, P, cp, return_xhat=True)
+    r = Xd.double() - xh                                                      # residuals, :77
+    a, b, c, d = cp[..., 0], cp[..., 1], cp[..., 2], cp[..., 3]               # each [3,3]
+    w = P[:, :3, None]                                                        # [N,3,1]
+    f = (a * torch.cos(b * w + c) + d).float().double()                       # .astype(np.float32), :66-73
+    df = (-a * b * torch.sin(b * w + c)).float().double()                     # :80-81,85-86,90-91
+    u = P[:, 3:]
+    ones = torch.ones_like(u)
+
+    def coef(uu, fy, fp, fr):
+        return torch.einsum("ni,nj,nk,nl->nijkl", uu, fy, fp, fr).reshape(P.shape[0], -1)
+
+    W64 = Wm.double()
+    g = r @ W64.T                                                             # [N,135]
+    gy = -(coef(u, df[:, 0], f[:, 1], f[:, 2]) * g).sum(1)
+    gp = -(coef(u, f[:, 0], df[:, 1], f[:, 2]) * g).sum(1)
+    gr = -(coef(u, f[:, 0], f[:, 1], df[:, 2]) * g).sum(1)
+    # 'ijklm,j,k,l->m' (:96) sums over i as well, and all its operands are f32, so numpy evaluates it in f32: v is an f32
+    # quantity in the reference (this part of the gradient is therefore pinned to f32 rounding only, ~1e-7 relative)
+    v = (coef(ones, f[:, 0], f[:, 1], f[:, 2]).float() @ Wm).double()
+    S = W64.reshape(5, 27, -1).sum(1)                                         # [5,1404]
+    gu = -((r * v) @ S.T)
+    return torch.cat([gy[:, None], gp[:, None], gr[:, None], gu], dim=1).cpu().numpy()
+
+
+def compute_gradient(params, W, x, params_y, params_p, params_r):
+    """Same signature as the reference (:60); x may be a torch tensor or an array.  -> f64[8]."""
+    return compute_gradient_batch(np.asarray(params, dtype=np.float64)[None], W, x, params_y, params_p, params_r)[0]
 
 
 def Test_batch(W, X, u_id_shape, optimized_params_y, optimized_params_p, optimized_params_r, return_info=False):

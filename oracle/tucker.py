@@ -76,3 +76,25 @@ def test_powell(W, x, u_id_shape, params_y, params_p, params_r, return_result=Fa
     deg = np.degrees(res.x)                                         # :196
     out = (deg[0], deg[1], deg[2])
     return (out, res) if return_result else out
+
+
+def compute_gradient(params, W, x, params_y, params_p, params_r):
+    """``compute_gradient`` :60-102, the analytic gradient handed to ``minimize(jac=...)`` at :194 (Powell ignores it).
+
+    Restated as written, including the identity-mode term exactly as the reference forms it (:96): the inner einsum
+    'ijklm,j,k,l->m' also sums over i."""
+    params = np.asarray(params, dtype=np.float64)
+    w_y, w_p, w_r = params[:3]
+    u_id = params[3:]
+    f_y, f_p, f_r = f_vectors(params, params_y, params_p, params_r)
+    xh = np.einsum('ijklm,i,j,k,l->m', W, u_id, f_y, f_p, f_r)
+    residuals = np.asarray(x) - xh
+
+    def dfun(w, rows):
+        return np.array([-p[0] * p[1] * np.sin(p[1] * w + p[2]) for p in rows]).flatten().astype(np.float32)
+
+    g_y = -np.sum(residuals * np.einsum('ijklm,i,j,k,l->m', W, u_id, dfun(w_y, params_y), f_p, f_r))
+    g_p = -np.sum(residuals * np.einsum('ijklm,i,j,k,l->m', W, u_id, f_y, dfun(w_p, params_p), f_r))
+    g_r = -np.sum(residuals * np.einsum('ijklm,i,j,k,l->m', W, u_id, f_y, f_p, dfun(w_r, params_r)))
+    g_u = -np.einsum('ijklm,m->i', W, residuals * np.einsum('ijklm,j,k,l->m', W, f_y, f_p, f_r))
+    return np.concatenate(([g_y, g_p, g_r], g_u))

@@ -15,6 +15,7 @@ What is imported from /root/reference and called (file:line of the callee):
   FX6  NLML_HPE_Test.py:62,95           compute_maev, compute_errors
   FX7  generatePose_on_video.py:73,128  visualize_axes_on_face, process_video (EMA loop)
   FX8  NLML_HPE_MLPHeadsTrainer.py:71   cosine (called in the loops of :179-205 on the config_MlpHeads.yaml grids)
+  FX9  TD_Tester.py:60                  compute_gradient (on the FX4 inputs)
 
 cv2 / mediapipe are not installed; empty stub modules satisfy the imports, and
 for FX7 the handful of cv2 / FaceMesh entry points process_video touches are
@@ -330,9 +331,22 @@ def fx8_cosine_table():
     print("FX8", {k: v.shape for k, v in out.items()})
 
 
+def fx9_td_gradient():
+    """The reference's analytic gradient on the FX4 inputs (same seeds => the test regenerates params and x from FX4)."""
+    import TD_Tester
+    n = 32
+    td, fm, W, idx, X = _tucker_inputs(n, seed=2)
+    P = synth.tucker_params(n, 5, seed=2)
+    P[0] = 0.0
+    Py, Pp, Pr = td["optimized_yaw"][0:3, :], td["optimized_pitch"][0:3, :], td["optimized_roll"][0:3, :]
+    G = np.stack([TD_Tester.compute_gradient(P[i], W, torch.from_numpy(X[i]), Py, Pp, Pr) for i in range(n)])
+    np.savez_compressed(os.path.join(HERE, "fx9_td_gradient.npz"), grad=G)
+    print("FX9 |grad| range", np.abs(G).min(), np.abs(G).max())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8"]
+    which = sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "7", "8", "9"]
     table = {"1": fx1_normalise, "2": fx2_heads, "3": fx3_encoder_heads, "4": fx4_td_objective,
-             "5": fx5_td_end_to_end, "6": fx6_metrics, "7": fx7_video_math, "8": fx8_cosine_table}
+             "5": fx5_td_end_to_end, "6": fx6_metrics, "7": fx7_video_math, "8": fx8_cosine_table, "9": fx9_td_gradient}
     for w in which:
         table[w]()

@@ -699,3 +699,22 @@ def test_mode5_product_on_device(tucker_art, device):
     rel_back = np.abs(back - core).max() / np.abs(core).max()
     _report("mode5_product", rel_vs_f64=rel, roundtrip_rel=rel_back)
     assert rel <= 2e-5 and rel_back <= 1e-4
+
+
+def test_fx9_td_gradient_on_device(tucker_art, golden_dir, device):
+    """compute_gradient (TD_Tester.py:60-102) on the device against FX9 (the reference's own numbers).  The three angle
+    derivatives are f64 end to end: tolerance 1e-10 of their scale (einsums regrouped into GEMMs, so rounding, not bits).
+    The identity-mode part contains an einsum whose operands are all f32 (:96), which numpy evaluates in f32 in its own
+    summation order: that part can only agree to f32 rounding, tolerance 1e-6 of its scale."""
+    from nlml_hpe_amd import TD_Tester as HT
+    g = np.load(os.path.join(golden_dir, "fx9_td_gradient.npz"))["grad"]
+    f = np.load(os.path.join(golden_dir, "fx4_td_objective.npz"))
+    Py, Pp, Pr = tucker_art["optimized_yaw"][:3], tucker_art["optimized_pitch"][:3], tucker_art["optimized_roll"][:3]
+    G = HT.compute_gradient_batch(f["params"], tucker_art["W"], f["x"], Py, Pp, Pr)
+    e_ang = np.abs(G[:, :3] - g[:, :3]).max() / np.abs(g[:, :3]).max()
+    e_uid = np.abs(G[:, 3:] - g[:, 3:]).max() / np.abs(g[:, 3:]).max()
+    one = HT.compute_gradient(f["params"][3], tucker_art["W"], torch.from_numpy(f["x"][3]), Py, Pp, Pr)
+    _report("fx9_td_gradient", angles_rel_of_scale=e_ang, u_id_rel_of_scale=e_uid)
+    assert e_ang <= 1e-10 and e_uid <= 1e-6, (e_ang, e_uid)
+    assert np.abs(one[:3] - g[3][:3]).max() <= 1e-10 * np.abs(g[:, :3]).max()
+    assert np.abs(one[3:] - g[3][3:]).max() <= 1e-6 * np.abs(g[:, 3:]).max()

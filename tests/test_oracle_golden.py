@@ -151,3 +151,24 @@ def test_mode5_product_oracle_forms_agree():
     assert np.abs(chain - W64).max() <= 5e-6 * np.abs(W64).max()
     back = np.tensordot(W64, Uf.astype(np.float64), axes=(4, 0))
     assert np.abs(back - core).max() <= 1e-5
+
+
+def test_fx9_td_gradient_oracle(golden_dir):
+    """FX9: the reference's compute_gradient (TD_Tester.py:60-102) on the FX4 inputs; the restatement uses the same numpy
+    calls, so it must reproduce the reference's numbers bit for bit."""
+    g = np.load(os.path.join(golden_dir, "fx9_td_gradient.npz"))["grad"]
+    f = np.load(os.path.join(golden_dir, "fx4_td_objective.npz"))
+    td = np.load(os.path.join(os.path.dirname(os.path.dirname(golden_dir)), "outputs", "features", "Trained_data.npz"))
+    Py, Pp, Pr = td["optimized_yaw"][:3], td["optimized_pitch"][:3], td["optimized_roll"][:3]
+    G = np.stack([TK.compute_gradient(f["params"][i], td["W"], f["x"][i], Py, Pp, Pr) for i in range(len(g))])
+    assert np.array_equal(G, g)
+    # and it IS the gradient of the objective in the three angles (central differences with h = 1e-3: the f-vectors are
+    # rounded to f32, so smaller steps only measure that rounding; the u_id part is the reference's own formula)
+    p = f["params"][5].copy()
+    for k in range(3):
+        h = 1e-3
+        pp, pm = p.copy(), p.copy()
+        pp[k] += h
+        pm[k] -= h
+        fd = (TK.objective(pp, td["W"], f["x"][5], Py, Pp, Pr) - TK.objective(pm, td["W"], f["x"][5], Py, Pp, Pr)) / (2 * h)
+        assert abs(fd - g[5][k]) <= 2e-3 * max(1.0, abs(g[5][k]))
