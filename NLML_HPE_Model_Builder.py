@@ -23,6 +23,8 @@ def model_builder(argv=None):
     ap.add_argument("--synthetic-encoder-seed", type=int, default=None,
                     help="use generator-G encoder weights when models/Encoder.pth is absent (the reference ships none)")
     ap.add_argument("--out", default="models/combined_model_packed.nlml")
+    ap.add_argument("--mode", choices=["f16x2", "f32", "bf16"], default="f16x2",
+                    help="kernel mode the blob is packed for (the forward entry points recognise it by the blob size)")
     args = ap.parse_args(argv)
 
     input_size = load_config("configs/config_EncoderTrainer.yaml")["input_size"]
@@ -38,10 +40,11 @@ def model_builder(argv=None):
         if args.synthetic_encoder_seed is None:
             raise
         enc = synth.encoder_state_dict(input_size, args.synthetic_encoder_seed)
-    blob = weights.pack_blob(enc, heads)
+    from nlml_hpe_amd import _lib
+    blob = weights.pack_blob(enc, heads, _lib.mode_from_name(args.mode))
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     np.asarray(blob).tofile(args.out)
-    print(f"model is built: {args.out} ({blob.nbytes} bytes, F={input_size})")
+    print(f"model is built: {args.out} ({blob.nbytes} bytes, F={input_size}, mode={args.mode})")
     return args.out
 
 
