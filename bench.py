@@ -313,6 +313,13 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     for name, b in (("f16x2", blob_hx), ("f32", blob)):
         ms = time_kernel(lambda: ops.landmarks_to_pose(r2k, b, True), 200, warm=50)
         ex[f"config4_2000_faces_step_{name}"] = {"ms_per_step": ms, "faces_per_sec": 2000 / ms * 1e3}
+    # the same step on the layer-per-launch path (same bits as the fused f16x2 kernel; what HIPPoseModel uses up to 4,096 faces)
+    ms = time_kernel(lambda: ops.landmarks_to_pose_small(r2k, blob_hx, True), 200, warm=50)
+    ex["config4_2000_faces_step_f16x2_layered"] = {"ms_per_step": ms, "faces_per_sec": 2000 / ms * 1e3}
+    r64 = raw[:64].contiguous()
+    ms_f = time_kernel(lambda: ops.landmarks_to_pose(r64, blob_hx, True), 200, warm=50)
+    ms_l = time_kernel(lambda: ops.landmarks_to_pose_small(r64, blob_hx, True), 200, warm=50)
+    ex["tick_64_faces_f16x2"] = {"fused_ms": ms_f, "layered_ms": ms_l}
     ms = time_kernel(lambda: ops.normalize_ipd(raw, True), 20)
     ex["k1_normalize"] = {"faces_per_sec": B / ms * 1e3, "gbs": B * BYTES_PER_FACE_K1 / ms / 1e6,
                           "hbm_frac": B * BYTES_PER_FACE_K1 / ms / 1e6 / PEAK_HBM_GBS}

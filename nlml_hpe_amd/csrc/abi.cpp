@@ -89,6 +89,31 @@ int nlml_landmarks_to_pose(const float* raw, int64_t B, int normalize, const voi
   return launch_encoder_heads_f32(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, nullptr, nullptr, stream);
 }
 
+// ---- split-f16 mode, one launch per layer (small batches) -------------------------------------------------------
+size_t nlml_encoder_heads_small_workspace_bytes(int64_t B, int F) { return small_workspace_bytes(B, F); }
+
+static int check_small(int64_t B, int F, const void* blob, size_t blob_bytes, const float* out) {
+  int mode = 0;
+  if (int rc = check_blob_args(B, F, blob, blob_bytes, out, &mode)) return rc;
+  if (mode != NLML_MODE_F16X2) return fail(NLML_E_BADARG, "small-batch path: NLML_MODE_F16X2 blob only");
+  return 0;
+}
+
+int nlml_encoder_heads_fwd_small(const float* x, int64_t ldx, int64_t B, int F, const void* blob, size_t blob_bytes,
+                                 float* out, float* latent, uint8_t* valid, void* workspace, size_t ws_bytes, void* stream) {
+  if (int rc = check_small(B, F, blob, blob_bytes, out)) return rc;
+  if (B > 0 && (!x || ldx < F)) return fail(NLML_E_BADARG, "encoder_heads: null x or ldx < F");
+  return launch_encoder_heads_f16x2_small(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, workspace, ws_bytes, stream);
+}
+
+int nlml_landmarks_to_pose_small(const float* raw, int64_t B, int normalize, const void* blob, size_t blob_bytes,
+                                 float* out, float* latent, uint8_t* valid, void* workspace, size_t ws_bytes, void* stream) {
+  if (int rc = check_small(B, NLML_F_REFERENCE, blob, blob_bytes, out)) return rc;
+  if (B > 0 && !raw) return fail(NLML_E_BADARG, "landmarks_to_pose: null raw");
+  return launch_encoder_heads_f16x2_small(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, workspace,
+                                          ws_bytes, stream);
+}
+
 int nlml_tucker_objective(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,
                           const double* params, const double* cos_params, int64_t N, double* err, double* x_hat,
                           void* stream) {

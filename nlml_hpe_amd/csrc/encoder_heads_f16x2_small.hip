@@ -1,0 +1,304 @@
+// encoder_heads_f16x2_small.hip -- K2 for SMALL batches (split-f16 parity mode), one launch per layer.
+//
+// The fused kernel (encoder_heads_f16x2.hip) walks one 64-face tile through the whole network on ONE CU, so a batch of
+// 64 faces (a video tick) or 2,000 faces (BASELINE config 4) keeps 1 or 32 of the 256 CUs busy and its latency is the
+// time to stream the 9.6 MB of weights through one CU (~0.17 ms).  Here every layer is its own launch over
+// (neuron blocks x face tiles): the weight stream of a layer is spread over up to 32 x tiles waves, activations pass
+// between the launches through a caller-provided workspace in MFMA-fragment order (so both operand streams are
+// coalesced 1-KiB loads, no LDS at all), and stream order is the only synchronisation (no spin-waits, graph-capturable).
+//
+// Arithmetic is the fused kernel's, operation for operation: the same blob (same hi/lo weight pieces and scales), the
+// same activation split, per output the same K-ascending sequence of the same three MFMAs -- the results are
+// bit-identical to the fused kernel's (tests/test_gpu_parity.py), so everything pinned there holds here.
+//
+// Workspace: two ping-pong buffers of ntiles x max(k16_e0, 64) K-steps x 4 KiB
+//   fragment (tile, step, face block fb, piece, lane) = 8 f16 = activations k = 16*step + 8*(lane>>5) .. +7 of face
+//   64*tile + 32*fb + (lane&31).
+#include <hip/hip_runtime.h>
+
+#include "../../include/nlml_hpe.h"
+#include "abi_internal.h"
+#include "layout.h"
+
+namespace nlml {
+namespace hxs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+constexpr int STEP_UNITS = 2 * 2 * 64;   // h8 units per (tile, K step): 2 face blocks x 2 pieces x 64 lanes = 4 KiB
+
+__device__ __forceinline__ float activate(int act, float v) {
+  if (act == ACT_RELU) return v < 0.0f ? 0.0f : v;
+  if (act == ACT_TANH) return tanhf(v);
+  return v;
+}
+
+__device__ __forceinline__ double div_ipd(double n, double d, double y) {
+  const double q = n * y;
+  const double r = fma(-q, d, n);
+  return fma(r, y, q);
+}
+
+// ---- pre-pass: x (f32 rows, or raw landmarks with optional IPD normalisation) -> hi/lo fragments of layer 0's input.
+// One wave per face; lane handles 8-column chunks c = lane, lane + 64, ... (chunk c = K step c/2, half c&1).
+__global__ __launch_bounds__(256) void prepass_kernel(const float* __restrict__ x, int64_t ldx, int64_t B, int F, int norm,
+                                                      int k16, int buf_steps, h8* __restrict__ ws,
+                                                      uint8_t* __restrict__ valid) {
+  const int lane = threadIdx.x & 63;
+  const int64_t face = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t tile = face >> 6;
+  const int fi = (int)(face & 63), fb = fi >> 5, f = fi & 31;
+  const bool live = face < B;
+  const float* p = x + (live ? face : B - 1) * ldx;
+  double ipd = 1.0, rcp = 1.0, ref0 = 0.0, ref1 = 0.0, ref2 = 0.0;
+  if (norm) {   // FeatureExtractor.py:30-66, exactly as K1 and the fused kernels do it
+    const double dx = (double)p[99] - (double)p[789], dy = (double)p[100] - (double)p[790], dz = (double)p[101] - (double)p[791];
+    ipd = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
+    if (ipd == 0.0) ipd = 1e-6;
+    rcp = 1.0 / ipd;
+    ref0 = (double)p[3]; ref1 = (double)p[4]; ref2 = (double)p[5];
+  }
+  unsigned nz = 0u;
+  for (int c = lane; c < 2 * k16; c += 64) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 8 * c + e;
+      float t = k < F ? p[k] : 0.0f;
+      const int ph = k % 3;
+      if (norm && k < F) t = (float)div_ipd((double)t - (ph == 0 ? ref0 : (ph == 1 ? ref1 : ref2)), ipd, rcp);
+      v[e] = t;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(v[e]));   // keep the f32 value (see encoder_heads_f16x2.hip)
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      nz |= __float_as_uint(v[e]) & 0x7fffffffu;
+      const _Float16 hv = (_Float16)v[e];
+      hi[e] = hv;
+      lo[e] = (_Float16)(v[e] - (float)hv);
+    }
+    if (live) {
+      h8* d = ws + ((size_t)tile * buf_steps + (c >> 1)) * STEP_UNITS + (size_t)(fb * 2) * 64 + f + 32 * (c & 1);
+      d[0] = hi;
+      d[64] = lo;
+    }
+  }
+  const unsigned long long any = __ballot(nz != 0u);
+  if (valid && live && lane == 0) valid[face] = any ? 1 : 0;
+}
+
+// ---- one layer.  Unit = (tile, job, group of NBW neuron blocks of the job); one wave per unit.
+struct LayerArgs {
+  const void* blob;
+  const h8* xin;
+  h8* xout;
+  float* pose;      // last head layer: f32[B,3]
+  float* latent;    // E5: f32[B,9] or null
+  int64_t B;
+  int stage, K16, nb_stage, jobs, ntiles, buf_steps, act;
+  int in_step0[12];   // first input K step of job j (its input column / 16)
+  int out_col0[12];   // first output column of job j
+};
+
+template <int NBW>
+__global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
+  const int lane = threadIdx.x & 63, f = lane & 31, h = lane >> 5;
+  const int groups = a.nb_stage / NBW;                     // units per (tile, job)
+  const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= (int64_t)a.ntiles * a.jobs * groups) return;    // whole wave leaves together
+  const int grp = (int)(u % groups), job = (int)((u / groups) % a.jobs);
+  const int64_t tile = u / ((int64_t)groups * a.jobs);
+  const int nb0 = grp * NBW;
+  const Header* hdr = reinterpret_cast<const Header*>(a.blob);
+  const h8* blob8 = reinterpret_cast<const h8*>(a.blob);
+  const f32x4* blob4 = reinterpret_cast<const f32x4*>(a.blob);
+  const int st = a.stage, NBS = a.nb_stage, K16 = a.K16;
+
+  f32x16 acc[NBW][2];
+  {  // bias in accumulator-register order (layout.h), scaled like the weights
+    const f32x4* b = blob4 + hdr->b_off[st] + (size_t)job * (NBS * 8);
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = b[((nb0 + i) * 2 + h) * 4 + q];
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) {
+          acc[i][fb][4 * q + 0] = v[0]; acc[i][fb][4 * q + 1] = v[1];
+          acc[i][fb][4 * q + 2] = v[2]; acc[i][fb][4 * q + 3] = v[3];
+        }
+      }
+  }
+  const h8* w = blob8 + hdr->w_off[st] + (size_t)job * hdr->job_w16[st] + (size_t)nb0 * 128 + lane;   // + step*NBS*128
+  const h8* xi = a.xin + ((size_t)tile * a.buf_steps + a.in_step0[job]) * STEP_UNITS + lane;          // + step*256
+
+  constexpr int R = 4, D = R - 1;
+  h8 wr[R][NBW][2], xr[R][2][2];
+  auto load = [&](int slot, int s) {
+    const h8* wp = w + (size_t)s * NBS * 128;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) wr[slot][i][p] = wp[(i * 2 + p) * 64];
+    const h8* xp = xi + (size_t)s * STEP_UNITS;
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) xr[slot][fb][p] = xp[(fb * 2 + p) * 64];
+  };
+  auto mma = [&](int slot) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int wp_ = t == 0 ? 1 : 0, xp_ = t == 1 ? 1 : 0;   // (lo,hi), (hi,lo), (hi,hi): the fused kernel's order
+#pragma unroll
+      for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+          acc[i][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[slot][i][wp_], xr[slot][fb][xp_], acc[i][fb], 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) load(d, d < K16 ? d : K16 - 1);
+  const int groups4 = K16 / R;
+  for (int g = 0; g < groups4; ++g) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int sp = g * R + r + D;
+      load((r + D) % R, sp < K16 ? sp : K16 - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(r);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  for (int r = 0; r < K16 - groups4 * R; ++r) {   // K16 = 1 (head input layer): slots 0..2 hold steps 0..2 (clamped)
+    if (r == 0) mma(0); else if (r == 1) mma(1); else mma(2);
+  }
+
+  const float inv = hdr->inv_scale[st];
+  if (a.pose) {   // last head layer (H4): the single output neuron is accumulator row 0 = register 0 of lanes 0..31
+    if (h == 0) {
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb) {
+        const int64_t face = tile * 64 + 32 * fb + f;
+        if (face < a.B) a.pose[face * 3 + job] = acc[0][fb][0] * inv;
+      }
+    }
+    return;
+  }
+  if (a.latent) {   // E5: latent n = 3g + c sits on row 16g + c
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int rowi = 32 * (nb0 + i) + (q & 3) + 8 * (q >> 2) + 4 * h, g = rowi >> 4, cc = rowi & 15;
+          const int64_t face = tile * 64 + 32 * fb + f;
+          if (g < 3 && cc < 3 && face < a.B) a.latent[face * NLML_LATENT + 3 * g + cc] = acc[i][fb][q] * inv;
+        }
+  }
+  // accumulators * inv -> activation -> hi/lo -> the next layer's input fragments
+#pragma unroll
+  for (int i = 0; i < NBW; ++i)
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = a.out_col0[job] + 32 * (nb0 + i) + 8 * q + 4 * h;   // this lane's 4 neurons n .. n+3
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = activate(a.act, acc[i][fb][4 * q + e] * inv);
+          const _Float16 hv = (_Float16)v;
+          hi[e] = hv;
+          lo[e] = (_Float16)(v - (float)hv);
+        }
+        h8* frag = a.xout + ((size_t)tile * a.buf_steps + (n >> 4)) * STEP_UNITS + (size_t)(fb * 2) * 64 + f + 32 * ((n >> 3) & 1);
+        _Float16* d = reinterpret_cast<_Float16*>(frag) + (n & 7);
+        *reinterpret_cast<h4*>(d) = hi;
+        *reinterpret_cast<h4*>(d + 64 * 8) = lo;
+      }
+}
+
+static int e0_k16(int F) { return (F + 2 * hx::XS_COLS - 1) / (2 * hx::XS_COLS) * (2 * hx::XS_STEPS); }   // as pack.cpp
+
+}  // namespace hxs
+
+size_t small_workspace_bytes(int64_t B, int F) {
+  if (B <= 0 || F <= 0) return 0;
+  const int64_t ntiles = (B + 63) / 64;
+  const int steps = hxs::e0_k16(F) > 64 ? hxs::e0_k16(F) : 64;
+  return (size_t)2 * ntiles * steps * hxs::STEP_UNITS * 16;
+}
+
+int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,
+                                     const void* blob, float* out, float* latent, uint8_t* valid, void* workspace,
+                                     size_t ws_bytes, void* stream) {
+  using namespace hxs;
+  if (B == 0) return 0;
+  if (ws_bytes < small_workspace_bytes(B, F) || !workspace) return fail(NLML_E_BADARG, "small-batch path: workspace too small");
+  if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail(NLML_E_BADARG, "small-batch path: workspace must be 16-byte aligned");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int ntiles = (int)((B + 63) / 64);
+  const int k16 = e0_k16(F);
+  const int buf_steps = k16 > 64 ? k16 : 64;
+  h8* bufA = reinterpret_cast<h8*>(workspace);
+  h8* bufB = bufA + (size_t)ntiles * buf_steps * STEP_UNITS;
+
+  const float* src = raw ? raw : x;
+  const int64_t sld = raw ? NLML_F_REFERENCE : ldx;
+  hipLaunchKernelGGL(prepass_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, src, sld, B, F, raw ? (normalize ? 1 : 0) : 0,
+                     k16, buf_steps, bufA, valid);
+
+  // stage table: {stage, K16, blocks per job, jobs, activation}; input/output columns as in the fused kernel
+  struct S { int stage, K16, nb, jobs, act; };
+  const S stages[NUM_STAGES] = {
+      {ST_E0, k16, 4, 8, ACT_RELU}, {ST_E1, 64, 4, 4, ACT_RELU}, {ST_E2, 32, 2, 4, ACT_RELU}, {ST_E3, 16, 1, 4, ACT_RELU},
+      {ST_E4, 8, 1, 2, ACT_TANH},   {ST_E5, 4, 2, 1, ACT_NONE},  {ST_H0, 1, 1, 12, ACT_RELU}, {ST_H1, 8, 2, 12, ACT_RELU},
+      {ST_H2, 16, 1, 12, ACT_RELU}, {ST_H3, 8, 1, 6, ACT_RELU},  {ST_H4, 4, 1, 3, ACT_NONE}};
+  h8* in = bufA;
+  h8* outb = bufB;
+  for (int s = 0; s < NUM_STAGES; ++s) {
+    LayerArgs a{};
+    a.blob = blob; a.xin = in; a.xout = outb; a.B = B; a.stage = stages[s].stage; a.K16 = stages[s].K16;
+    a.nb_stage = stages[s].nb; a.jobs = stages[s].jobs; a.ntiles = ntiles; a.buf_steps = buf_steps; a.act = stages[s].act;
+    a.pose = (s == ST_H4) ? out : nullptr;
+    a.latent = (s == ST_E5) ? latent : nullptr;
+    for (int j = 0; j < a.jobs; ++j) {
+      int in_col = 0, out_col = 0;
+      switch (s) {
+        case ST_E0: case ST_E1: out_col = 128 * j; break;
+        case ST_E2: out_col = 64 * j; break;
+        case ST_E3: case ST_E4: out_col = 32 * j; break;
+        case ST_E5: out_col = 0; break;
+        case ST_H0: in_col = 16 * (j >> 2); out_col = 128 * (j >> 2) + 32 * (j & 3); break;
+        case ST_H1: in_col = 128 * (j >> 2); out_col = 256 * (j >> 2) + 64 * (j & 3); break;
+        case ST_H2: in_col = 256 * (j >> 2); out_col = 128 * (j >> 2) + 32 * (j & 3); break;
+        case ST_H3: in_col = 128 * (j >> 1); out_col = 64 * (j >> 1) + 32 * (j & 1); break;
+        case ST_H4: in_col = 64 * j; break;
+      }
+      a.in_step0[j] = in_col / 16;
+      a.out_col0[j] = out_col;
+    }
+    // blocks per wave: as many as still leave enough waves to keep the weight loads of every CU in flight
+    int nbw = a.nb_stage;
+    constexpr int kMinUnits = 2048;   // measured: 8 waves per CU keep enough loads in flight (256 units: 153 us at B = 2,000; 2,048: 114 us)
+    while (nbw > 1 && (int64_t)ntiles * a.jobs * (a.nb_stage / nbw) < kMinUnits) nbw >>= 1;
+    const int64_t units = (int64_t)ntiles * a.jobs * (a.nb_stage / nbw);
+    const dim3 grid((unsigned)((units + 3) / 4)), block(256);
+    if (nbw == 4) hipLaunchKernelGGL((layer_kernel<4>), grid, block, 0, st, a);
+    else if (nbw == 2) hipLaunchKernelGGL((layer_kernel<2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((layer_kernel<1>), grid, block, 0, st, a);
+    h8* t = in; in = outb; outb = t;
+  }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
+}  // namespace nlml

@@ -62,16 +62,25 @@ class HIPPoseModel:
         """x f32[B,F] -> f32[B,3] radians (+ latent [B,9], + valid mask: row not all-zero)."""
         if x.dim() == 1:
             x = x.unsqueeze(0)
-        return ops.encoder_heads_fwd(x.to(self.device, torch.float32), self.blob, self.input_size,
-                                     return_latent=return_latent, return_valid=return_valid)
+        fwd = ops.encoder_heads_fwd_small if self._small(x.shape[0]) else ops.encoder_heads_fwd
+        return fwd(x.to(self.device, torch.float32), self.blob, self.input_size,
+                   return_latent=return_latent, return_valid=return_valid)
+
+    SMALL_BATCH_MAX = 4096
+
+    def _small(self, B: int) -> bool:
+        """Split-f16 mode, up to SMALL_BATCH_MAX faces: the layer-per-launch path (same bits as the fused kernel, 0.09-0.16 ms
+        instead of 0.17 ms because a handful of 64-face tiles cannot fill 256 CUs with one CU per tile)."""
+        return self.mode == _lib.MODE_F16X2 and 0 < B <= self.SMALL_BATCH_MAX
 
     def from_landmarks(self, raw: torch.Tensor, normalize: bool = True, return_latent: bool = False,
                        return_valid: bool = False):
         """raw FaceMesh landmarks f32[B,468,3] -> f32[B,3] radians, normalisation fused into the launch."""
         if self.input_size != ops.F_REF:
             raise ValueError("from_landmarks needs the reference input width 1404")
-        return ops.landmarks_to_pose(raw.to(self.device, torch.float32), self.blob, normalize,
-                                     return_latent=return_latent, return_valid=return_valid)
+        fwd = ops.landmarks_to_pose_small if self._small(raw.shape[0]) else ops.landmarks_to_pose
+        return fwd(raw.to(self.device, torch.float32), self.blob, normalize,
+                   return_latent=return_latent, return_valid=return_valid)
 
 
 def load_model(path_or_dir: str = "models", device=None, encoder_state_dict: dict | None = None,

@@ -257,3 +257,71 @@ def mode5_product(core: torch.Tensor, U_feat: torch.Tensor) -> torch.Tensor:
     _lib.check(_lib.lib().nlml_mode5_product(c2.data_ptr(), U_feat.data_ptr(), Q, R5, M, W.data_ptr(), _stream_ptr()),
                "nlml_mode5_product")
     return W.reshape(lead + (M,))
+
+
+_small_ws: dict = {}
+
+
+def _small_workspace(B: int, F: int, device) -> torch.Tensor:
+    """Scratch for the layer-per-launch path, cached per device and grown on demand (its contents never matter)."""
+    need = _lib.lib().nlml_encoder_heads_small_workspace_bytes(B, F)
+    key = str(device)
+    ws = _small_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((need,), dtype=torch.uint8, device=device)
+        _small_ws[key] = ws
+    return ws
+
+
+def encoder_heads_fwd_small(x: torch.Tensor, blob: torch.Tensor, F: int, return_latent: bool = False,
+                            return_valid: bool = False, workspace: torch.Tensor | None = None):
+    """encoder_heads_fwd for small batches (split-f16 blob only): one launch per layer, bit-identical results."""
+    _need_cuda(x, "x", torch.float32)
+    _need_cuda(blob, "blob", torch.uint8)
+    if x.dim() != 2 or x.shape[1] != F:
+        raise ValueError(f"x: expected [B,{F}], got {tuple(x.shape)}")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    B = x.shape[0]
+    ldx = x.stride(0) if B > 1 else F
+    ws = workspace if workspace is not None else _small_workspace(B, F, x.device)
+    out = torch.empty((B, 3), dtype=torch.float32, device=x.device)
+    latent = torch.empty((B, LATENT), dtype=torch.float32, device=x.device) if return_latent else None
+    valid = torch.empty((B,), dtype=torch.uint8, device=x.device) if return_valid else None
+    _lib.check(_lib.lib().nlml_encoder_heads_fwd_small(
+        x.data_ptr(), ldx, B, F, blob.data_ptr(), blob.numel(), out.data_ptr(),
+        latent.data_ptr() if latent is not None else None,
+        valid.data_ptr() if valid is not None else None, ws.data_ptr(), ws.numel(), _stream_ptr()),
+        "nlml_encoder_heads_fwd_small")
+    res = [out]
+    if return_latent:
+        res.append(latent)
+    if return_valid:
+        res.append(valid.bool())
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+def landmarks_to_pose_small(raw: torch.Tensor, blob: torch.Tensor, normalize: bool = True, return_latent: bool = False,
+                            return_valid: bool = False, workspace: torch.Tensor | None = None):
+    """landmarks_to_pose for small batches (split-f16 blob only): one launch per layer, bit-identical results."""
+    _need_cuda(raw, "raw", torch.float32)
+    _need_cuda(blob, "blob", torch.uint8)
+    if raw.dim() != 3 or raw.shape[1:] != (468, 3):
+        raise ValueError(f"raw: expected [B,468,3], got {tuple(raw.shape)}")
+    raw = raw.contiguous()
+    B = raw.shape[0]
+    ws = workspace if workspace is not None else _small_workspace(B, F_REF, raw.device)
+    out = torch.empty((B, 3), dtype=torch.float32, device=raw.device)
+    latent = torch.empty((B, LATENT), dtype=torch.float32, device=raw.device) if return_latent else None
+    valid = torch.empty((B,), dtype=torch.uint8, device=raw.device) if return_valid else None
+    _lib.check(_lib.lib().nlml_landmarks_to_pose_small(
+        raw.data_ptr(), B, int(bool(normalize)), blob.data_ptr(), blob.numel(), out.data_ptr(),
+        latent.data_ptr() if latent is not None else None,
+        valid.data_ptr() if valid is not None else None, ws.data_ptr(), ws.numel(), _stream_ptr()),
+        "nlml_landmarks_to_pose_small")
+    res = [out]
+    if return_latent:
+        res.append(latent)
+    if return_valid:
+        res.append(valid.bool())
+    return res[0] if len(res) == 1 else tuple(res)

@@ -718,3 +718,72 @@ def test_fx9_td_gradient_on_device(tucker_art, golden_dir, device):
     assert e_ang <= 1e-10 and e_uid <= 1e-6, (e_ang, e_uid)
     assert np.abs(one[:3] - g[3][:3]).max() <= 1e-10 * np.abs(g[:, :3]).max()
     assert np.abs(one[3:] - g[3][3:]).max() <= 1e-6 * np.abs(g[:, 3:]).max()
+
+
+# ---- split-f16 mode, one launch per layer (small batches) ---------------------------------------------------------
+@pytest.mark.parametrize("F,B", [(1404, 1), (1404, 64), (1404, 65), (1404, 200), (1404, 2000), (136, 77), (13, 5), (1407, 130)])
+def test_small_batch_path_is_bit_identical_to_the_fused_kernel(F, B, head_sds, device):
+    """nlml_encoder_heads_fwd_small runs every layer as its own launch over (neuron blocks x tiles) with activations in a
+    workspace; per output it issues the same MFMAs in the same order as the fused split-f16 kernel, so pose, latent and
+    validity must be the same bits (and with them every parity result of the fused kernel carries over)."""
+    sd = synth.encoder_state_dict(F, seed=3)
+    blob = _blob_hx(sd, head_sds, device)
+    x = synth.features(B, F, seed=9)
+    if B > 3:
+        x[3] = 0.0
+    xt = torch.from_numpy(x).to(device)
+    a, la, va = ops.encoder_heads_fwd(xt, blob, F, return_latent=True, return_valid=True)
+    b, lb, vb = ops.encoder_heads_fwd_small(xt, blob, F, return_latent=True, return_valid=True)
+    assert torch.equal(a, b) and torch.equal(la, lb) and torch.equal(va, vb)
+    ref = EH.forward_numpy(x, EH.Params(sd, head_sds), np.float64)
+    assert np.degrees(np.abs(b.cpu().numpy() - ref).max()) <= POSE_TOL_DEG
+
+
+def test_small_batch_path_landmarks_workspace_and_errors(head_sds, device):
+    """Raw-landmark entry of the small-batch path: same bits as the fused launch incl. the validity mask; garbage (NaN)
+    in the workspace and in the dead faces of a partial tile does not leak; wrong blob mode / short workspace are refused."""
+    from nlml_hpe_amd import _lib
+    sd = synth.encoder_state_dict(1404, seed=0)
+    blob = _blob_hx(sd, head_sds, device)
+    raw = synth.raw_landmarks(131, seed=17)
+    raw[3] = np.array([0.25, 0.5, 0.75], np.float32)
+    raw[64] = 0.0
+    rt = torch.from_numpy(raw).to(device)
+    a, va = ops.landmarks_to_pose(rt, blob, True, return_valid=True)
+    need = _lib.lib().nlml_encoder_heads_small_workspace_bytes(131, 1404)
+    ws = torch.full((need,), 0xFF, dtype=torch.uint8, device=device)          # every f16 in it is a NaN
+    b, vb = ops.landmarks_to_pose_small(rt, blob, True, return_valid=True, workspace=ws)
+    assert torch.equal(a, b) and torch.equal(va, vb)
+    c = ops.landmarks_to_pose_small(rt, blob, False, workspace=ws)
+    assert torch.equal(c, ops.landmarks_to_pose(rt, blob, False))
+    with pytest.raises(_lib.NlmlError):
+        ops.landmarks_to_pose_small(rt, blob, True, workspace=ws[: need // 2])
+    with pytest.raises(_lib.NlmlError):
+        ops.landmarks_to_pose_small(rt, _blob(sd, head_sds, device), True)    # f32 blob: split-f16 only
+
+
+def test_model_dispatches_small_batches_and_graph_replays(head_sds, device):
+    """HIPPoseModel in split-f16 mode uses the small-batch path up to SMALL_BATCH_MAX faces (same bits either way), and
+    the 12-launch sequence replays from a hipGraph."""
+    from nlml_hpe_amd.model import HIPPoseModel
+    sd = synth.encoder_state_dict(1404, seed=0)
+    model = HIPPoseModel(sd, head_sds, device=device)
+    raw = torch.from_numpy(synth.raw_landmarks(300, seed=8)).to(device)
+    assert model._small(300) and not model._small(model.SMALL_BATCH_MAX + 1)
+    assert torch.equal(model.from_landmarks(raw), ops.landmarks_to_pose(raw, model.blob, True))
+    feats = ops.normalize_ipd(raw, True)
+    assert torch.equal(model.forward_packed(feats), ops.encoder_heads_fwd(feats, model.blob, 1404))
+    static_in = raw.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            model.from_landmarks(static_in)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_out = model.from_landmarks(static_in)
+    static_in.copy_(torch.from_numpy(synth.raw_landmarks(300, seed=9)).to(device))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, ops.landmarks_to_pose(static_in, model.blob, True))
