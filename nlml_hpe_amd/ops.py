@@ -263,13 +263,17 @@ _small_ws: dict = {}
 
 
 def _small_workspace(B: int, F: int, device) -> torch.Tensor:
-    """Scratch for the layer-per-launch path, cached per device and grown on demand (its contents never matter)."""
+    """Scratch for the layer-per-launch path (its contents never matter).  Buffers are cached per device and NEVER
+    released or replaced: a captured hipGraph keeps replaying into the pointer it was captured with, so growing means
+    adding a larger buffer next to the old one.  The first one is sized for 4,096 faces of the reference width (46 MB)."""
     need = _lib.lib().nlml_encoder_heads_small_workspace_bytes(B, F)
-    key = str(device)
-    ws = _small_ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty((need,), dtype=torch.uint8, device=device)
-        _small_ws[key] = ws
+    pool = _small_ws.setdefault(str(device), [])
+    for ws in pool:
+        if ws.numel() >= need:
+            return ws
+    size = max(need, _lib.lib().nlml_encoder_heads_small_workspace_bytes(4096, F_REF))
+    ws = torch.empty((size,), dtype=torch.uint8, device=device)
+    pool.append(ws)
     return ws
 
 
