@@ -263,11 +263,12 @@ _small_ws: dict = {}
 
 
 def _small_workspace(B: int, F: int, device) -> torch.Tensor:
-    """Scratch for the layer-per-launch path (its contents never matter).  Buffers are cached per device and NEVER
+    """Scratch for the layer-per-launch path (its contents never matter).  Buffers are cached per device and stream and NEVER
     released or replaced: a captured hipGraph keeps replaying into the pointer it was captured with, so growing means
     adding a larger buffer next to the old one.  The first one is sized for 4,096 faces of the reference width (46 MB)."""
     need = _lib.lib().nlml_encoder_heads_small_workspace_bytes(B, F)
-    pool = _small_ws.setdefault(str(device), [])
+    # one pool per (device, stream): launches on different streams may overlap and must not share scratch
+    pool = _small_ws.setdefault((str(device), _stream_ptr()), [])
     for ws in pool:
         if ws.numel() >= need:
             return ws
