@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
   const h8* w = blob8 + hdr->w_off[st] + (size_t)job * hdr->job_w16[st] + (size_t)nb0 * 128 + lane;   // + step*NBS*128
   const h8* xi = a.xin + ((size_t)tile * a.buf_steps + a.in_step0[job]) * STEP_UNITS + lane;          // + step*256
 
+  // ring of 4 steps; deeper rings (8 at NBW = 1) changed nothing: at 64 faces the 12 launches (~6 us each) dominate
   constexpr int R = 4, D = R - 1;
   h8 wr[R][NBW][2], xr[R][2][2];
   auto load = [&](int slot, int s) {
@@ -176,9 +177,10 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  for (int r = 0; r < K16 - groups4 * R; ++r) {   // K16 = 1 (head input layer): slots 0..2 hold steps 0..2 (clamped)
-    if (r == 0) mma(0); else if (r == 1) mma(1); else mma(2);
-  }
+  const int tail = K16 - groups4 * R;   // steps groups4*R + r sit in slot r (loaded D steps earlier, or by the prologue)
+#pragma unroll
+  for (int r = 0; r < R - 1; ++r)
+    if (r < tail) mma(r);
 
   const float inv = hdr->inv_scale[st];
   if (a.pose) {   // last head layer (H4): the single output neuron is accumulator row 0 = register 0 of lanes 0..31
