@@ -11,7 +11,6 @@ from __future__ import annotations
 import argparse
 import time
 
-import numpy as np
 import torch
 
 from nlml_hpe_amd import TD_Tester, ops, weights

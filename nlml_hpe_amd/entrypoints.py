@@ -10,7 +10,7 @@ import warnings
 import numpy as np
 import yaml
 
-from . import synth, weights
+from . import synth
 from .model import HIPPoseModel, load_model
 
 
