@@ -2,10 +2,12 @@
 //
 // The fused kernel (encoder_heads_f16x2.hip) walks one 64-face tile through the whole network on ONE CU, so a batch of
 // 64 faces (a video tick) or 2,000 faces (BASELINE config 4) keeps 1 or 32 of the 256 CUs busy and its latency is the
-// time to stream the 9.6 MB of weights through one CU (~0.17 ms).  Here every layer is its own launch over
-// (neuron blocks x face tiles): the weight stream of a layer is spread over up to 32 x tiles waves, activations pass
-// between the launches through a caller-provided workspace in MFMA-fragment order (so both operand streams are
-// coalesced 1-KiB loads, no LDS at all), and stream order is the only synchronisation (no spin-waits, graph-capturable).
+// time to stream the 9.6 MB of weights through one CU (~0.17 ms).  Here the three big layers (E0, E1, E2: 93 % of the
+// weights) are each their own launch over (neuron blocks x face tiles): the weight stream of a layer is spread over up
+// to 32 x tiles waves, activations pass between the launches through a caller-provided workspace in MFMA-fragment
+// order (so both operand streams are coalesced 1-KiB loads, no LDS), and stream order is the only synchronisation (no
+// spin-waits, graph-capturable).  The small tail (E3, E4, E5, heads) is one more launch: a workgroup per tile runs the
+// fused kernel's own tail_stages().  Five launches in all: pre-pass, E0, E1, E2, tail.
 //
 // Arithmetic is the fused kernel's, operation for operation: the same blob (same hi/lo weight pieces and scales), the
 // same activation split, per output the same K-ascending sequence of the same three MFMAs -- the results are
@@ -18,17 +20,19 @@
 
 #include "../../include/nlml_hpe.h"
 #include "abi_internal.h"
+#include "encoder_heads_f16x2_dev.h"
 #include "layout.h"
 
 namespace nlml {
 namespace hxs {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+using hx::f32x16;
+using hx::f32x4;
+using hx::h4;
+using hx::h8;
+using hx::ACT_NONE;
+using hx::ACT_RELU;
+using hx::ACT_TANH;
 constexpr int STEP_UNITS = 2 * 2 * 64;   // h8 units per (tile, K step): 2 face blocks x 2 pieces x 64 lanes = 4 KiB
 
 __device__ __forceinline__ float activate(int act, float v) {
@@ -98,19 +102,19 @@ struct LayerArgs {
   const void* blob;
   const h8* xin;
   h8* xout;
-  float* pose;      // last head layer: f32[B,3]
-  float* latent;    // E5: f32[B,9] or null
   int64_t B;
   int stage, K16, nb_stage, jobs, ntiles, buf_steps, act;
   int in_step0[12];   // first input K step of job j (its input column / 16)
   int out_col0[12];   // first output column of job j
 };
 
-template <int NBW>
+// R = depth of the operand ring.  With few units (one wave per CU) a unit's rate is its own loads in flight, so those
+// launches use 64-thread workgroups (the units spread over the CUs instead of sharing one four at a time) and R = 8.
+template <int NBW, int R>
 __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
   const int lane = threadIdx.x & 63, f = lane & 31, h = lane >> 5;
   const int groups = a.nb_stage / NBW;                     // units per (tile, job)
-  const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t u = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (u >= (int64_t)a.ntiles * a.jobs * groups) return;    // whole wave leaves together
   const int grp = (int)(u % groups), job = (int)((u / groups) % a.jobs);
   const int64_t tile = u / ((int64_t)groups * a.jobs);
@@ -138,8 +142,7 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
   const h8* w = blob8 + hdr->w_off[st] + (size_t)job * hdr->job_w16[st] + (size_t)nb0 * 128 + lane;   // + step*NBS*128
   const h8* xi = a.xin + ((size_t)tile * a.buf_steps + a.in_step0[job]) * STEP_UNITS + lane;          // + step*256
 
-  // ring of 4 steps; deeper rings (8 at NBW = 1) changed nothing: at 64 faces the 12 launches (~6 us each) dominate
-  constexpr int R = 4, D = R - 1;
+  constexpr int D = R - 1;
   h8 wr[R][NBW][2], xr[R][2][2];
   auto load = [&](int slot, int s) {
     const h8* wp = w + (size_t)s * NBS * 128;
@@ -183,28 +186,6 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
     if (r < tail) mma(r);
 
   const float inv = hdr->inv_scale[st];
-  if (a.pose) {   // last head layer (H4): the single output neuron is accumulator row 0 = register 0 of lanes 0..31
-    if (h == 0) {
-#pragma unroll
-      for (int fb = 0; fb < 2; ++fb) {
-        const int64_t face = tile * 64 + 32 * fb + f;
-        if (face < a.B) a.pose[face * 3 + job] = acc[0][fb][0] * inv;
-      }
-    }
-    return;
-  }
-  if (a.latent) {   // E5: latent n = 3g + c sits on row 16g + c
-#pragma unroll
-    for (int i = 0; i < NBW; ++i)
-#pragma unroll
-      for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int rowi = 32 * (nb0 + i) + (q & 3) + 8 * (q >> 2) + 4 * h, g = rowi >> 4, cc = rowi & 15;
-          const int64_t face = tile * 64 + 32 * fb + f;
-          if (g < 3 && cc < 3 && face < a.B) a.latent[face * NLML_LATENT + 3 * g + cc] = acc[i][fb][q] * inv;
-        }
-  }
   // accumulators * inv -> activation -> hi/lo -> the next layer's input fragments
 #pragma unroll
   for (int i = 0; i < NBW; ++i)
@@ -226,6 +207,33 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
         *reinterpret_cast<h4*>(d) = hi;
         *reinterpret_cast<h4*>(d + 64 * 8) = lo;
       }
+}
+
+// ---- the network's tail (E3, E4, E5 and the three heads: 8 of the 11 layers, 7 % of the FLOP) as ONE launch: a
+// workgroup per 64-face tile copies E2's output fragments into the H3 LDS image and runs the fused kernel's
+// tail_stages() on it.  Eight layer launches (~6 us each at small batches) become one.
+__global__ __launch_bounds__(256, 1) void tail_kernel(hx::Args a, const h8* __restrict__ xin, int buf_steps) {
+  __shared__ __attribute__((aligned(16))) char lds[hx::LDS_BYTES];
+  const int tid = threadIdx.x;
+  hx::Ctx c;
+  c.blob8 = reinterpret_cast<const h8*>(a.blob);
+  c.blob4 = reinterpret_cast<const f32x4*>(a.blob);
+  c.hdr = reinterpret_cast<const Header*>(a.blob);
+  c.lds = lds;
+  c.lane = tid & 63;
+  c.f = c.lane & 31;
+  c.h = c.lane >> 5;
+  c.wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t tile = blockIdx.x, row0 = tile * TILE_FACES;
+  // fragment (step, fb, piece, lane) -> image row 32*fb + (lane & 31), columns 16*step + 8*(lane >> 5) .. +7 of plane `piece`
+  const h8* src = xin + (size_t)tile * buf_steps * STEP_UNITS;
+  for (int i = tid; i < 16 * STEP_UNITS; i += 256) {          // E2's output: 256 columns = 16 K steps
+    const int l = i & 63, piece = (i >> 6) & 1, fb = (i >> 7) & 1, step = i >> 8;
+    const int face = 32 * fb + (l & 31), k = 16 * step + 8 * (l >> 5);
+    *reinterpret_cast<h8*>(lds + hx::O_H3 + piece * hx::P_H3 + (face * hx::S_H3 + k) * 2) = src[i];
+  }
+  __syncthreads();
+  hx::tail_stages(c, a, row0);
 }
 
 static int e0_k16(int F) { return (F + 2 * hx::XS_COLS - 1) / (2 * hx::XS_COLS) * (2 * hx::XS_STEPS); }   // as pack.cpp
@@ -258,46 +266,41 @@ int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* r
   hipLaunchKernelGGL(prepass_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, src, sld, B, F, raw ? (normalize ? 1 : 0) : 0,
                      k16, buf_steps, bufA, valid);
 
-  // stage table: {stage, K16, blocks per job, jobs, activation}; input/output columns as in the fused kernel
-  struct S { int stage, K16, nb, jobs, act; };
-  const S stages[NUM_STAGES] = {
-      {ST_E0, k16, 4, 8, ACT_RELU}, {ST_E1, 64, 4, 4, ACT_RELU}, {ST_E2, 32, 2, 4, ACT_RELU}, {ST_E3, 16, 1, 4, ACT_RELU},
-      {ST_E4, 8, 1, 2, ACT_TANH},   {ST_E5, 4, 2, 1, ACT_NONE},  {ST_H0, 1, 1, 12, ACT_RELU}, {ST_H1, 8, 2, 12, ACT_RELU},
-      {ST_H2, 16, 1, 12, ACT_RELU}, {ST_H3, 8, 1, 6, ACT_RELU},  {ST_H4, 4, 1, 3, ACT_NONE}};
+  // the three big layers: {stage, K16, blocks per job, jobs}; ReLU; job j covers output columns 32 * blocks * j ..
+  struct S { int stage, K16, nb, jobs; };
+  const S stages[3] = {{ST_E0, k16, 4, 8}, {ST_E1, 64, 4, 4}, {ST_E2, 32, 2, 4}};
   h8* in = bufA;
   h8* outb = bufB;
-  for (int s = 0; s < NUM_STAGES; ++s) {
+  for (int s = 0; s < 3; ++s) {
     LayerArgs a{};
     a.blob = blob; a.xin = in; a.xout = outb; a.B = B; a.stage = stages[s].stage; a.K16 = stages[s].K16;
-    a.nb_stage = stages[s].nb; a.jobs = stages[s].jobs; a.ntiles = ntiles; a.buf_steps = buf_steps; a.act = stages[s].act;
-    a.pose = (s == ST_H4) ? out : nullptr;
-    a.latent = (s == ST_E5) ? latent : nullptr;
+    a.nb_stage = stages[s].nb; a.jobs = stages[s].jobs; a.ntiles = ntiles; a.buf_steps = buf_steps; a.act = hx::ACT_RELU;
     for (int j = 0; j < a.jobs; ++j) {
-      int in_col = 0, out_col = 0;
-      switch (s) {
-        case ST_E0: case ST_E1: out_col = 128 * j; break;
-        case ST_E2: out_col = 64 * j; break;
-        case ST_E3: case ST_E4: out_col = 32 * j; break;
-        case ST_E5: out_col = 0; break;
-        case ST_H0: in_col = 16 * (j >> 2); out_col = 128 * (j >> 2) + 32 * (j & 3); break;
-        case ST_H1: in_col = 128 * (j >> 2); out_col = 256 * (j >> 2) + 64 * (j & 3); break;
-        case ST_H2: in_col = 256 * (j >> 2); out_col = 128 * (j >> 2) + 32 * (j & 3); break;
-        case ST_H3: in_col = 128 * (j >> 1); out_col = 64 * (j >> 1) + 32 * (j & 1); break;
-        case ST_H4: in_col = 64 * j; break;
-      }
-      a.in_step0[j] = in_col / 16;
-      a.out_col0[j] = out_col;
+      a.in_step0[j] = 0;
+      a.out_col0[j] = 32 * a.nb_stage * j;
     }
     // blocks per wave: as many as still leave enough waves to keep the weight loads of every CU in flight
     int nbw = a.nb_stage;
     constexpr int kMinUnits = 2048;   // measured: 8 waves per CU keep enough loads in flight (256 units: 153 us at B = 2,000; 2,048: 114 us)
     while (nbw > 1 && (int64_t)ntiles * a.jobs * (a.nb_stage / nbw) < kMinUnits) nbw >>= 1;
     const int64_t units = (int64_t)ntiles * a.jobs * (a.nb_stage / nbw);
-    const dim3 grid((unsigned)((units + 3) / 4)), block(256);
-    if (nbw == 4) hipLaunchKernelGGL((layer_kernel<4>), grid, block, 0, st, a);
-    else if (nbw == 2) hipLaunchKernelGGL((layer_kernel<2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((layer_kernel<1>), grid, block, 0, st, a);
+    if (units < 1024) {   // fewer than four waves per CU: one wave per workgroup, deep ring
+      const dim3 grid((unsigned)units), block(64);
+      if (nbw == 4) hipLaunchKernelGGL((layer_kernel<4, 6>), grid, block, 0, st, a);
+      else if (nbw == 2) hipLaunchKernelGGL((layer_kernel<2, 8>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((layer_kernel<1, 8>), grid, block, 0, st, a);
+    } else {
+      const dim3 grid((unsigned)((units + 3) / 4)), block(256);
+      if (nbw == 4) hipLaunchKernelGGL((layer_kernel<4, 4>), grid, block, 0, st, a);
+      else if (nbw == 2) hipLaunchKernelGGL((layer_kernel<2, 4>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((layer_kernel<1, 4>), grid, block, 0, st, a);
+    }
     h8* t = in; in = outb; outb = t;
+  }
+  {
+    hx::Args ta{};
+    ta.B = B; ta.F = F; ta.blob = blob; ta.out = out; ta.latent = latent; ta.valid = nullptr;
+    hipLaunchKernelGGL(tail_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, ta, (const h8*)in, buf_steps);
   }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
