@@ -26,7 +26,7 @@ int launch_encoder_heads_bf16(const float* x, int64_t ldx, const float* raw, int
 int launch_encoder_heads_f16x2(const float* x, int64_t ldx, const float* raw, int normalize,
                                int64_t B, int F, const void* blob, float* out, float* latent,
                                uint8_t* valid, void* stream);
-// encoder_heads_f16x2_small.hip (split-f16 mode, one launch per layer, for small batches)
+// encoder_heads_f16x2_small.hip (split-f16 mode, big layers as separate launches + one tail launch, for small batches)
 size_t small_workspace_bytes(int64_t B, int F);
 int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,
                                      const void* blob, float* out, float* latent, uint8_t* valid, void* workspace,

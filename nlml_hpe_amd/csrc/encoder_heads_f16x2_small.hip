@@ -1,4 +1,4 @@
-// encoder_heads_f16x2_small.hip -- K2 for SMALL batches (split-f16 parity mode), one launch per layer.
+// encoder_heads_f16x2_small.hip -- K2 for SMALL batches (split-f16 parity mode): the big layers as separate launches.
 //
 // The fused kernel (encoder_heads_f16x2.hip) walks one 64-face tile through the whole network on ONE CU, so a batch of
 // 64 faces (a video tick) or 2,000 faces (BASELINE config 4) keeps 1 or 32 of the 256 CUs busy and its latency is the
