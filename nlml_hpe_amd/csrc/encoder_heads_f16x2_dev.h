@@ -297,44 +297,52 @@ __device__ __forceinline__ void job_store(const Ctx& c, const f32x16 (&acc)[NB][
 // ------------------------------------------------------------------------------------------
 // Layers E3 .. H4 of one 64-face tile (rows row0 .. row0+63): input = the H3 image (E2's output, hi/lo planes at O_H3),
 // output = poses (and the latent) in global memory.  All 256 threads of the workgroup call it after a barrier.
-__device__ __forceinline__ void tail_stages(const Ctx& c, const Args& a, int64_t row0) {
+// ONEFB = true (small-batch path): the workgroup handles only the 32-face block `fbsel` of the tile (another workgroup
+// takes the other one): the same MFMAs per face block -- faces are MFMA columns -- in fewer sequential stages.
+template <bool ONEFB = false>
+__device__ __forceinline__ void tail_stages(const Ctx& c, const Args& a, int64_t row0, int fbsel = 0) {
   const int wv = c.wv;
-  {  // E3: 256 -> 128, ReLU
+  if constexpr (ONEFB) {  // E3: 256 -> 128, ReLU, this face block only
+    f32x16 acc[1][1];
+    job_compute<1, 1, ST_E3>(c, wv, acc, O_H3, P_H3, S_H3, 0, 32 * fbsel);
+    job_store<1, 1, ACT_RELU>(c, acc, O_H4, P_H4, S_H4, 32 * wv, 32 * fbsel, c.hdr->inv_scale[ST_E3]);
+  } else {  // E3: 256 -> 128, ReLU
     f32x16 acc[1][2];
     job_compute<1, 2, ST_E3>(c, wv, acc, O_H3, P_H3, S_H3, 0, 0);
     job_store<1, 2, ACT_RELU>(c, acc, O_H4, P_H4, S_H4, 32 * wv, 0, c.hdr->inv_scale[ST_E3]);
   }
   __syncthreads();
   HXS(11);
-  {  // E4: 128 -> 64, Tanh; neuron block wv&1, face block wv>>1
-    const int nb = wv & 1, face0 = 32 * (wv >> 1);
+  if (!ONEFB || wv < 2) {  // E4: 128 -> 64, Tanh; neuron block wv&1, face block wv>>1 (ONEFB: waves 0,1 on block fbsel)
+    const int nb = wv & 1, face0 = ONEFB ? 32 * fbsel : 32 * (wv >> 1);
     f32x16 acc[1][1];
     job_compute<1, 1, ST_E4>(c, nb, acc, O_H4, P_H4, S_H4, 0, face0);
     job_store<1, 1, ACT_TANH>(c, acc, O_H5, P_H5, S_H5, 32 * nb, face0, c.hdr->inv_scale[ST_E4]);
   }
   __syncthreads();
-  if (wv < 2) {  // E5: 64 -> 9, latent n = 3g+c on row 16g+c (2 blocks), other rows exact zeros; face block wv
+  const int fb5 = ONEFB ? fbsel : wv;   // E5's face block: wave wv of waves 0,1; ONEFB: wave 0 on block fbsel
+  if (ONEFB ? wv == 0 : wv < 2) {  // E5: 64 -> 9, latent n = 3g+c on row 16g+c (2 blocks), other rows exact zeros
     f32x16 acc[2][1];
-    job_compute<2, 1, ST_E5>(c, 0, acc, O_H5, P_H5, S_H5, 0, 32 * wv);
+    job_compute<2, 1, ST_E5>(c, 0, acc, O_H5, P_H5, S_H5, 0, 32 * fb5);
     const float inv = c.hdr->inv_scale[ST_E5];
 #ifndef HX_STAMPS
-    if (a.latent && row0 + 32 * wv + c.f < a.B) {   // f32 latent straight from the accumulators
+    if (a.latent && row0 + 32 * fb5 + c.f < a.B) {   // f32 latent straight from the accumulators
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int rowi = 32 * nb + (q & 3) + 8 * (q >> 2) + 4 * c.h, g = rowi >> 4, cc = rowi & 15;
-          if (g < 3 && cc < 3) a.latent[(row0 + 32 * wv + c.f) * NLML_LATENT + 3 * g + cc] = acc[nb][0][q] * inv;
+          if (g < 3 && cc < 3) a.latent[(row0 + 32 * fb5 + c.f) * NLML_LATENT + 3 * g + cc] = acc[nb][0][q] * inv;
         }
     }
 #endif
-    job_store<2, 1, ACT_NONE, S_LAT>(c, acc, O_LAT, P_LAT, S_LAT, 0, 32 * wv, inv);
+    job_store<2, 1, ACT_NONE, S_LAT>(c, acc, O_LAT, P_LAT, S_LAT, 0, 32 * fb5, inv);
   }
   __syncthreads();
   HXS(12);
   // ---- heads, one 32-face block at a time; the jobs a wave owns run together (kloop_grouped)
 #pragma unroll 1
-  for (int fb = 0; fb < 2; ++fb) {
+  for (int fb = ONEFB ? fbsel : 0; fb < (ONEFB ? fbsel + 1 : 2); ++fb) {
     const int face0 = 32 * fb;
     {  // H0: 3 -> 128 (K padded to 16 with zeros), ReLU
       constexpr int ST = ST_H0;

@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
 }
 
 // ---- the network's tail (E3, E4, E5 and the three heads: 8 of the 11 layers, 7 % of the FLOP) as ONE launch: a
-// workgroup per 64-face tile copies E2's output fragments into the H3 LDS image and runs the fused kernel's
-// tail_stages() on it.  Eight layer launches (~6 us each at small batches) become one.
+// workgroup per 32-FACE BLOCK copies its half of E2's output fragments into the H3 LDS image and runs the fused
+// kernel's tail_stages() on that block (two workgroups per tile: half the sequential stages of the 64-face form).
 __global__ __launch_bounds__(256, 1) void tail_kernel(hx::Args a, const h8* __restrict__ xin, int buf_steps) {
   __shared__ __attribute__((aligned(16))) char lds[hx::LDS_BYTES];
   const int tid = threadIdx.x;
@@ -224,16 +224,19 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(hx::Args a, const h8* __re
   c.f = c.lane & 31;
   c.h = c.lane >> 5;
   c.wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t tile = blockIdx.x, row0 = tile * TILE_FACES;
+  const int64_t tile = blockIdx.x >> 1, row0 = tile * TILE_FACES;
+  const int fbsel = blockIdx.x & 1;
+  if (row0 + 32 * fbsel >= a.B) return;                       // no live face in this block (whole workgroup leaves)
   // fragment (step, fb, piece, lane) -> image row 32*fb + (lane & 31), columns 16*step + 8*(lane >> 5) .. +7 of plane `piece`
   const h8* src = xin + (size_t)tile * buf_steps * STEP_UNITS;
-  for (int i = tid; i < 16 * STEP_UNITS; i += 256) {          // E2's output: 256 columns = 16 K steps
-    const int l = i & 63, piece = (i >> 6) & 1, fb = (i >> 7) & 1, step = i >> 8;
-    const int face = 32 * fb + (l & 31), k = 16 * step + 8 * (l >> 5);
-    *reinterpret_cast<h8*>(lds + hx::O_H3 + piece * hx::P_H3 + (face * hx::S_H3 + k) * 2) = src[i];
+  for (int i = tid; i < 16 * 128; i += 256) {                 // E2's output: 256 columns = 16 K steps, this face block
+    const int l = i & 63, piece = (i >> 6) & 1, step = i >> 7;
+    const int face = 32 * fbsel + (l & 31), k = 16 * step + 8 * (l >> 5);
+    *reinterpret_cast<h8*>(lds + hx::O_H3 + piece * hx::P_H3 + (face * hx::S_H3 + k) * 2) =
+        src[(size_t)step * STEP_UNITS + (fbsel * 2 + piece) * 64 + l];
   }
   __syncthreads();
-  hx::tail_stages(c, a, row0);
+  hx::tail_stages<true>(c, a, row0, fbsel);
 }
 
 static int e0_k16(int F) { return (F + 2 * hx::XS_COLS - 1) / (2 * hx::XS_COLS) * (2 * hx::XS_STEPS); }   // as pack.cpp
@@ -300,7 +303,7 @@ int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* r
   {
     hx::Args ta{};
     ta.B = B; ta.F = F; ta.blob = blob; ta.out = out; ta.latent = latent; ta.valid = nullptr;
-    hipLaunchKernelGGL(tail_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, ta, (const h8*)in, buf_steps);
+    hipLaunchKernelGGL(tail_kernel, dim3((unsigned)(2 * ntiles)), dim3(256), 0, st, ta, (const h8*)in, buf_steps);
   }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));

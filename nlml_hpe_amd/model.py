@@ -69,7 +69,7 @@ class HIPPoseModel:
     SMALL_BATCH_MAX = 4096
 
     def _small(self, B: int) -> bool:
-        """Split-f16 mode, up to SMALL_BATCH_MAX faces: the layer-per-launch path (same bits as the fused kernel, 0.09-0.16 ms
+        """Split-f16 mode, up to SMALL_BATCH_MAX faces: the layer-per-launch path (same bits as the fused kernel, 0.06-0.13 ms
         instead of 0.17 ms because a handful of 64-face tiles cannot fill 256 CUs with one CU per tile)."""
         return self.mode == _lib.MODE_F16X2 and 0 < B <= self.SMALL_BATCH_MAX
 
