@@ -787,3 +787,22 @@ def test_model_dispatches_small_batches_and_graph_replays(head_sds, device):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(static_out, ops.landmarks_to_pose(static_in, model.blob, True))
+
+
+def test_empty_batches_are_no_ops_in_every_k2_path(head_sds, device):
+    """B = 0 (an empty shard, a tick with no faces): every K2 entry returns empty results without launching."""
+    from nlml_hpe_amd import _lib
+    from nlml_hpe_amd.model import HIPPoseModel
+    sd = synth.encoder_state_dict(1404, seed=0)
+    x0 = torch.empty((0, 1404), dtype=torch.float32, device=device)
+    r0 = torch.empty((0, 468, 3), dtype=torch.float32, device=device)
+    for mode in ("f32", "f16x2", "bf16"):
+        blob = torch.from_numpy(weights.pack_blob(sd, head_sds, _lib.mode_from_name(mode))).to(device)
+        assert tuple(ops.encoder_heads_fwd(x0, blob, 1404).shape) == (0, 3)
+        out, lat, val = ops.landmarks_to_pose(r0, blob, True, return_latent=True, return_valid=True)
+        assert tuple(out.shape) == (0, 3) and tuple(lat.shape) == (0, 9) and tuple(val.shape) == (0,)
+    blob = _blob_hx(sd, head_sds, device)
+    assert tuple(ops.encoder_heads_fwd_small(x0, blob, 1404).shape) == (0, 3)
+    assert tuple(ops.landmarks_to_pose_small(r0, blob, True).shape) == (0, 3)
+    model = HIPPoseModel(sd, head_sds, device=device)
+    assert tuple(model.from_landmarks(r0).shape) == (0, 3) and tuple(model.forward_packed(x0).shape) == (0, 3)
