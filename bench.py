@@ -2,7 +2,10 @@
 """bench.py -- faces/sec of the NLML_HPE batched-inference hot path on N MI355X GPUs.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 works both ways: under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+    (RANK/LOCAL_RANK/WORLD_SIZE from the env), or as a plain `python bench.py --gpus N ...`, which starts the N ranks itself
+    as child processes BEFORE anything touches the GPU and relays rank 0's JSON line.
+    BASELINE config 4 (2,000 faces per GPU, looped, with and without the collective):  python bench.py --gpus 8 --batch 2000
 
 One STEP = one pass of the hot path over one batch that is already resident in HBM:
 raw landmarks f32[B,468,3] -> IPD normalisation -> encoder -> 3 heads -> (yaw,pitch,roll) f32[B,3],
@@ -10,7 +13,8 @@ one fused HIP launch per rank (nlml_landmarks_to_pose), B = 65,536 faces per GPU
 F = 1404 (the reference's real feature width).  --mode picks the parity kernel: f16x2 (default: split-f16
 operands on the f16 matrix cores, f32 accumulate, ~1e-5 deg from the reference) or f32 (f32 matrix cores).  With N > 1 every
 step also all-gathers the [B,3] poses of all ranks over RCCL (the only collective the path has),
-on the communication stream, overlapped with the next step's compute.
+on the communication stream, overlapped with the next step's compute; a second timed region of K steps without
+the collective gives `value_no_collective` (--no-collective: time only that one).
 
 Prints ONE JSON line (rank 0): the contract fields plus
   roofline      the fused kernel against the dense MFMA peak of its operand type,
@@ -60,6 +64,8 @@ def parse():
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="that many untimed steps (~1 ms each) BEFORE the W warm-up steps, so that short K/W also measure "
                          "the sustained (power-limited) rate; reported in the JSON as config.settle_ms")
+    ap.add_argument("--no-collective", action="store_true",
+                    help="N > 1: no all-gather in the timed steps (default: time with it and report value_no_collective beside)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -79,14 +85,49 @@ def time_kernel(fn, iters, warm=3):
     return float(np.mean([a.elapsed_time(b) for a, b in evs]))  # ms
 
 
+def spawn_ranks(n: int, script: str = None, argv: list = None) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of THIS process, which has not
+    touched the GPU (importing torch does not initialise HIP; nothing above calls torch.cuda), wait for them, relay rank 0's
+    stdout (the JSON line) and return non-zero if any rank failed.  Children are started, never exec'ed into."""
+    import socket
+    import subprocess
+    script = os.path.abspath(__file__) if script is None else script
+    argv = sys.argv[1:] if argv is None else argv
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # rank 0 inherits stdout (its JSON line is the result); the other ranks print nothing there, keep them on stderr
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in pending:              # exactly the PIDs started above
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # NLML_BENCH_REHEARSAL=1: exercise the N>1 code path on a box with fewer GPUs than ranks (gloo instead of
     # RCCL, ranks share devices).  For checking the plumbing only -- never a measurement.
@@ -113,16 +154,21 @@ def main():
     heads = weights.load_head_state_dicts(os.path.join(ROOT, "models"))
     sd = synth.encoder_state_dict(F, seed=0)
     from nlml_hpe_amd import _lib
+    from nlml_hpe_amd.model import HIPPoseModel
     mode = _lib.MODE_F16X2 if args.mode == "f16x2" else _lib.MODE_F32
     blob = torch.from_numpy(weights.pack_blob(sd, heads, mode)).to(dev)
     raw_np = synth.raw_landmarks(B, seed=1 + rank)           # each rank owns its own shard of faces
     raw = torch.from_numpy(raw_np).to(dev)
     feats = ops.normalize_ipd(raw, True)
 
+    # up to SMALL_BATCH_MAX faces the split-f16 mode runs layer per launch (what HIPPoseModel does; same bits as the fused kernel)
+    layered = args.mode == "f16x2" and 0 < B <= HIPPoseModel.SMALL_BATCH_MAX
     if args.path == "fused":
-        step_fn = lambda: ops.landmarks_to_pose(raw, blob, True)
+        fwd = ops.landmarks_to_pose_small if layered else ops.landmarks_to_pose
+        step_fn = lambda: fwd(raw, blob, True)
     else:
-        step_fn = lambda: ops.encoder_heads_fwd(feats, blob, F)
+        fwd = ops.encoder_heads_fwd_small if layered else ops.encoder_heads_fwd
+        step_fn = lambda: fwd(feats, blob, F)
 
     gatherer = PoseGatherer(B, world, dev) if world > 1 else None
 
@@ -130,59 +176,75 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def run_steps(n, events=None):
+    def run_steps(n, events=None, collective=True):
+        g = gatherer if collective else None
         for i in range(n):
             if events is not None:
                 events[i][0].record()
             out = step_fn()
             if events is not None:
                 events[i][1].record()
-            if gatherer is not None:
-                gatherer.submit(out)
-        if gatherer is not None:
-            gatherer.drain()
+            if g is not None:
+                g.submit(out)
+        if g is not None:
+            g.drain()
 
-    if args.settle_ms > 0:                      # clock/power settling, untimed (see --settle-ms).  A FIXED number of steps
-        run_steps(int(args.settle_ms))          # (~1 ms each), identical on every rank: the steps contain a collective
+    def timed_region(collective):
+        """W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; MAX over ranks."""
+        run_steps(args.warmup, collective=collective)
         torch.cuda.synchronize()
-    run_steps(args.warmup)
-    torch.cuda.synchronize()
-    barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps, evs)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+        barrier()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(args.steps, evs, collective=collective)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0].item()), float(t[1].item())
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    kt = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
-    kern_ms = float(kt.item())
+    with_coll = world > 1 and not args.no_collective
+    # 1. the cold figure: W warm-ups + K steps straight after start-up, before any settling (what `--settle-ms 0` reads)
+    cold_elapsed, cold_kern_ms = timed_region(with_coll) if args.settle_ms > 0 else (None, None)
+    # 2. clock/power settling, untimed (see --settle-ms).  A FIXED number of steps, identical on every rank: the steps
+    #    contain a collective
+    if args.settle_ms > 0:
+        run_steps(int(args.settle_ms), collective=with_coll)
+        torch.cuda.synchronize()
+    # 3. the reported region
+    elapsed, kern_ms = timed_region(with_coll)
+    # 4. BASELINE config 4 "with and without the collective": the same K steps with no all-gather
+    nocoll_elapsed = timed_region(False)[0] if with_coll else None
 
     if rank == 0:
         value = world * B * args.steps / elapsed
         achieved = B * FLOP_PER_FACE[F] / (kern_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):
+        traffic, traffic_source = None, None
+        for tag in ("r02", "r01"):
+            tpath = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+            if not os.path.exists(tpath) or layered:
+                continue
             try:
-                traffic = json.load(open(tpath)).get(f"{args.mode}_{args.path}_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"{args.mode}_{args.path}_bytes_per_launch")
+                if traffic is not None:
+                    traffic_source = (f"from profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc passes of this command at B=65536, "
+                                      f"kernel_ms {tj.get(f'{args.mode}_{args.path}_kernel_ms')}); not re-measured in this run")
+                    break
             except Exception:
                 traffic = None
         if args.mode == "f16x2":
-            peak, kernel = PEAK_F16_MFMA_TFLOPS, "encoder_heads_f16x2_kernel"
+            peak = PEAK_F16_MFMA_TFLOPS
+            kernel = "k2s_* (pre, E0, E1, E2, tail: 5 launches)" if layered else "encoder_heads_f16x2_kernel"
             roof_extra = {"executed_flop_per_launch": SPLIT_PRODUCTS * B * FLOP_PER_FACE[F],
                           "executed_frac": SPLIT_PRODUCTS * achieved / peak,
                           "note": "each algorithmic product runs as 3 f16 MFMA products (hi*hi + hi*lo + lo*hi, f32 accumulate); "
-                                  "frac counts the algorithmic FLOP only; the kernel is limited by the L2->CU weight stream and "
-                                  "stage prologues, not by the matrix pipe (DESIGN.md)"}
+                                  "frac counts the algorithmic FLOP only; at 65,536 faces the kernel runs at the board's power "
+                                  "limit (clock ~1.9 GHz instead of 2.4), see DESIGN.md section 3"}
             dtype = "f16x2"
             what = "split-f16 parity mode (two f16 pieces per f32 operand, f32 accumulate)"
         else:
@@ -192,22 +254,29 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: gloo, shared devices -- not a measurement)",
-            "config": {"workload": f"landmarks->pose, batch {B}/GPU, F=1404 (468x3 landmarks), encoder+3 heads fused HIP forward, "
-                                   f"{what}, path={args.path}",
+            "config": {"workload": f"landmarks->pose, batch {B}/GPU, F=1404 (468x3 landmarks), encoder+3 heads "
+                                   f"{'layer-per-launch' if layered else 'fused'} HIP forward, {what}, path={args.path}",
                        "faces_per_gpu": B, "F": F, "path": args.path, "mode": args.mode, "settle_ms": args.settle_ms,
                        "seeds": {"encoder": 0, "landmarks": "1+rank"},
-                       "collective": "all_gather f32[B,3] per step" if world > 1 else "none"},
+                       "collective": "all_gather f32[B,3] per step" if with_coll else "none"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel, "kernel_ms": kern_ms,
                          "flop_per_launch": B * FLOP_PER_FACE[F],
                          "hbm_frac": B * (BYTES_PER_FACE_K2[F]) / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, **roof_extra},
         }
+        if cold_elapsed is not None:
+            rec["value_cold"] = world * B * args.steps / cold_elapsed
+            rec["cold_note"] = (f"value_cold = the same K={args.steps} steps after only W={args.warmup} warm-ups, straight after "
+                                f"start-up; value = after {int(args.settle_ms)} more untimed steps (sustained, power-limited rate)")
+        if nocoll_elapsed is not None:
+            rec["value_no_collective"] = world * B * args.steps / nocoll_elapsed
+            rec["ms_per_step_no_collective"] = nocoll_elapsed / args.steps * 1e3
         if world == 1 and not args.no_cpu_baseline:
             sample = np.arange(0, B, max(1, B // 2048))[:2048]
             got = step_fn()[torch.from_numpy(sample).to(dev)].cpu().numpy()
             rec["cpu_baseline"] = cpu_baseline(raw_np, sd, heads, args.cpu_seconds, sample, got)
-        if world == 1 and not args.no_extra:
+        if world == 1 and not args.no_extra and B == 65536:    # the secondary workloads are defined on the 65,536-face batch
             rec["extra"] = extra_workloads(ops, synth, weights, dev, heads, sd, raw, feats, B)
         print(json.dumps(rec), flush=True)
     if dist is not None:

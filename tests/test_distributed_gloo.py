@@ -42,3 +42,42 @@ def test_shard_and_gather_world2(tmp_path, repo_root):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert res.stdout.count("ok") == 2
+
+
+SPAWN_WORKER = r'''
+import os, sys, time
+import torch, torch.distributed as dist
+mode = sys.argv[1]
+r = int(os.environ["RANK"])
+assert int(os.environ["LOCAL_RANK"]) == r and os.environ["MASTER_ADDR"] == "127.0.0.1"
+if mode == "fail":
+    if r == 1:
+        sys.exit(3)
+    time.sleep(60)              # rank 0 must be stopped by the launcher, not run to the end
+    sys.exit(0)
+dist.init_process_group("gloo")
+t = torch.tensor([float(r + 1)])
+dist.all_reduce(t)
+if r == 0:
+    print('{"n_gpus": %d, "sum": %g}' % (dist.get_world_size(), float(t)), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_bench_self_launch_spawns_ranks_and_propagates_failure(tmp_path, repo_root):
+    """`python bench.py --gpus N` without a launcher (bench.spawn_ranks): N children with the torchrun env contract, rank 0's
+    stdout relayed, any failing rank makes the launcher return non-zero and stops the others."""
+    script = tmp_path / "spawn_worker.py"
+    script.write_text(SPAWN_WORKER)
+    drv = ("import sys; sys.path.insert(0, %r); import bench; "
+           "sys.exit(bench.spawn_ranks(2, script=%r, argv=[sys.argv[1]]))" % (repo_root, str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    ok = subprocess.run([sys.executable, "-c", drv, "ok"], env=env, capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stdout + ok.stderr
+    lines = [l for l in ok.stdout.splitlines() if l.startswith("{")]
+    assert lines == ['{"n_gpus": 2, "sum": 3}'], ok.stdout
+    import time
+    t0 = time.time()
+    bad = subprocess.run([sys.executable, "-c", drv, "fail"], env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 3, (bad.returncode, bad.stderr)
+    assert time.time() - t0 < 45, "the surviving rank was not stopped"
