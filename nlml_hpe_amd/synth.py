@@ -42,20 +42,60 @@ def _uniform_f32(g: np.random.Generator, shape, lo: float, hi: float) -> np.ndar
     return (lo + (hi - lo) * g.random(shape)).astype(np.float32)
 
 
-def encoder_state_dict(input_size: int = F_REFERENCE, seed: int = 0) -> dict:
+def encoder_state_dict(input_size: int = F_REFERENCE, seed: int = 0, hidden_weight_gain: float = 1.0) -> dict:
     """Synthetic encoder weights under the reference's state-dict keys.
 
     Keys ``encoder.{0,2,4,6,8,10}.{weight,bias}``, weight [out,in] f32 -- the
     layout ``LandmarkEncoder.load_state_dict`` expects
     (NLML_HPE_Model_Builder.py:33-53,202).
+
+    hidden_weight_gain multiplies the WEIGHTS (not the biases) of the five hidden layers.  PyTorch's default init
+    shrinks the face-to-face variation by ~0.4 per ReLU layer, so the default encoder's latent barely depends on the
+    face (std 0.007); gain 2.0 keeps the variation alive through the stack (a conditioning closer to a trained
+    encoder's), which is what the reference-range fixture FX3b uses.  The gain is a power of two, so it is exact.
     """
     g = rng(seed, _STREAM_ENCODER)
     sd = {}
     fan_in = int(input_size)
     for i, width in enumerate(ENCODER_WIDTHS):
         bound = 1.0 / np.sqrt(fan_in)
-        sd[f"encoder.{2 * i}.weight"] = _uniform_f32(g, (width, fan_in), -bound, bound)
+        w = _uniform_f32(g, (width, fan_in), -bound, bound)
+        if i < len(ENCODER_WIDTHS) - 1 and hidden_weight_gain != 1.0:
+            w = w * np.float32(hidden_weight_gain)
+        sd[f"encoder.{2 * i}.weight"] = w
         sd[f"encoder.{2 * i}.bias"] = _uniform_f32(g, (width,), -bound, bound)
+        fan_in = width
+    return sd
+
+
+def passthrough_encoder_state_dict(input_size: int = 136, out_gain: float = 2.0) -> dict:
+    """An encoder that hands its first nine inputs through to the latent: latent_i = out_gain * tanh(x_i).
+
+    Layer 0 forms relu(x_i) and relu(-x_i) (i < 9), the hidden layers carry those 18 non-negative values unchanged,
+    the Tanh layer recombines them into x_i and the last layer multiplies by out_gain.  With x_i = atanh(z_i / out_gain)
+    the three heads see z -- which is how fixture FX2b puts the heads' own operating points (rows of U_yaw/U_pitch/U_roll
+    and the trained cosine curves, tests/golden/fx2_heads.npz) through the whole fused forward on the GPU.
+    """
+    sd = {}
+    fan_in = int(input_size)
+    if fan_in < 9:
+        raise ValueError("passthrough encoder needs at least 9 inputs")
+    for i, width in enumerate(ENCODER_WIDTHS):
+        w = np.zeros((width, fan_in), np.float32)
+        if i == 0:
+            for k in range(9):
+                w[k, k], w[9 + k, k] = 1.0, -1.0
+        elif i < 4:
+            for k in range(18):
+                w[k, k] = 1.0
+        elif i == 4:
+            for k in range(9):
+                w[k, k], w[k, 9 + k] = 1.0, -1.0
+        else:
+            for k in range(9):
+                w[k, k] = out_gain
+        sd[f"encoder.{2 * i}.weight"] = w
+        sd[f"encoder.{2 * i}.bias"] = np.zeros((width,), np.float32)
         fan_in = width
     return sd
 

@@ -1,0 +1,25 @@
+"""Rebuild the inputs and weights of the reference-range fixtures (FX3b, FX2b) -- test helper.
+
+The fixtures hold the reference's outputs plus the few tensors that cannot be regenerated from a seed
+(tests/golden/make_golden.py: fx3b_reference_range, fx2b_heads_through_model)."""
+import os
+
+import numpy as np
+
+from nlml_hpe_amd import synth
+
+
+def fx3b(golden_dir):
+    """-> (g, encoder state dict, x f32[256,1404]); g["rad"] = the reference's batched output on exactly these."""
+    g = np.load(os.path.join(golden_dir, "fx3b_reference_range.npz"))
+    sd = synth.encoder_state_dict(1404, seed=0, hidden_weight_gain=2.0)
+    sd["encoder.10.weight"], sd["encoder.10.bias"] = g["enc10_weight"], g["enc10_bias"]
+    x = synth.features(256, 1404, seed=21)
+    assert float(x.astype(np.float64).sum()) == g["x_crc"][0]
+    return g, sd, x
+
+
+def fx2b(golden_dir):
+    """-> (g, encoder state dict, x f32[61,136]); the pass-through encoder puts FX2's head inputs on the latent."""
+    g = np.load(os.path.join(golden_dir, "fx2b_heads_through_model.npz"))
+    return g, synth.passthrough_encoder_state_dict(136, 2.0), g["x"]
