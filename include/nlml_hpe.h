@@ -73,8 +73,10 @@ int nlml_normalize_ipd(const float* raw, int64_t B, int normalize,
  *       ~5x the faces/s; its error is ~0.1 deg max / 0.02 deg mean and is never claimed as parity);
  *       NLML_MODE_F16X2 = split-f16 parity mode: every f32 weight and activation is carried as two f16
  *       pieces (hi + lo, 22 significand bits) and a product runs as three f16 MFMAs with f32 accumulation.
- *       Same <=1e-4 deg bar as NLML_MODE_F32 (measured ~1e-5 deg), ~2x its faces/s; |activation| must stay
- *       below 65504 (f16 range) -- a face that exceeds it yields NaN, never a silently wrong pose.
+ *       Same <=1e-4 deg bar as NLML_MODE_F32 (measured ~1e-5 deg), ~2.6x its faces/s.  No input-range limit: a
+ *       face whose activations leave f16's range (|v| >= 65520 -- e.g. the reference's ipd == 0 -> 1e-6 branch,
+ *       FeatureExtractor.py:47-48) is re-evaluated inside the same launch in f32 on the vector ALUs from the same
+ *       blob (csrc/encoder_heads_f16x2_rescue.h); NaN/Inf inputs give a non-finite pose, as in the reference.
  * The forward entry points recognise the mode of a blob by its size.
  */
 #define NLML_MODE_F32   0
@@ -178,7 +180,8 @@ int nlml_tucker_powell(const float* Wm, const float* x, int64_t ldx, const doubl
  * 100-px jump gate, and the three axis end points (size 80).
  *   pose_rad  f32[S,3]      this tick's model output (radians)
  *   raw       f32[S,468,3]  this tick's FaceMesh landmarks (only 1, 33, 263 are read)
- *   valid     u8[S] or NULL 0 = no face in this stream's frame: state and outputs untouched (:193-196)
+ *   valid     u8[S] or NULL 0 = no face in this stream's frame: state and outputs untouched (:193-196); a stream whose
+ *                           pose_rad holds NaN/Inf is skipped the same way (the reference would raise at :121)
  *   state     f64[S,6]      persistent: smoothed yaw/pitch/roll, previous centre x/y, prediction count;
  *                           zero-initialise before the first tick
  *   smoothed  f64[S,3] degrees; centre f64[S,2] pixels; endpoints f64[S,3,2] pixels (x,y of the red,

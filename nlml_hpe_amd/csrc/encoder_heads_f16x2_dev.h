@@ -258,6 +258,18 @@ struct Ctx {
   int lane, f, h, wv;
 };
 
+}  // namespace hx
+}  // namespace nlml
+#include "encoder_heads_f16x2_rescue.h"
+namespace nlml {
+namespace hx {
+
+// "this face's pose came out non-finite": one f16 slot per face in the latent image's hi plane, column 48 -- E5's store
+// writes exact zeros there (columns 48..55 belong to zero-padded accumulator rows) and no head reads them.
+__device__ __forceinline__ unsigned short* rescue_flag(char* lds, int face) {
+  return reinterpret_cast<unsigned short*>(lds + O_LAT + (face * S_LAT + 48) * 2);
+}
+
 // bias + K loop of one job whose input image (hi plane at byte offset in_off, row stride in_stride f16) is in LDS
 template <int NB, int NFB, int STAGE>
 __device__ __forceinline__ void job_compute(const Ctx& c, int job, f32x16 (&acc)[NB][NFB], int in_off, int plane,
@@ -428,11 +440,24 @@ __device__ __forceinline__ void tail_stages(const Ctx& c, const Args& a, int64_t
     if (wv < 3) {  // H4: 64 -> 1; neuron on accumulator row 0 = register 0 of lanes 0..31
       f32x16 acc[1][1];
       job_compute<1, 1, ST_H4>(c, wv, acc, O_HD, P_HD, S_HD, 64 * wv, 0);
-      if (c.h == 0 && row0 + face0 + c.f < a.B) a.out[(row0 + face0 + c.f) * 3 + wv] = acc[0][0][0] * c.hdr->inv_scale[ST_H4];
+      if (c.h == 0 && row0 + face0 + c.f < a.B) {
+        const float pose = acc[0][0][0] * c.hdr->inv_scale[ST_H4];
+        a.out[(row0 + face0 + c.f) * 3 + wv] = pose;
+        if (!__builtin_isfinite(pose)) *rescue_flag(c.lds, face0 + c.f) = 1;   // an activation left f16's range (or the input is NaN/Inf)
+      }
     }
     __syncthreads();
     HXS(17 + 5 * fb);
   }
+#if !defined(HX_STAMPS) && !defined(HX_NO_RESCUE)
+  {  // faces whose pose is non-finite take the f32 slow path (encoder_heads_f16x2_rescue.h); normally none
+    const int fl = ONEFB ? 32 * fbsel + c.f : c.lane;
+    const bool mine = ONEFB ? c.h == 0 : true;
+    const unsigned long long m = __ballot(mine && row0 + fl < a.B && *rescue_flag(c.lds, fl) != 0);
+    const unsigned long long mask = ONEFB ? (m & 0xffffffffull) << (32 * fbsel) : m;
+    if (mask) rescue_tile(a.x, a.ldx, a.F, a.norm, a.blob, a.out, a.latent, c.lds, row0, mask);
+  }
+#endif
 }
 
 }  // namespace hx

@@ -303,6 +303,7 @@ int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* r
   {
     hx::Args ta{};
     ta.B = B; ta.F = F; ta.blob = blob; ta.out = out; ta.latent = latent; ta.valid = nullptr;
+    ta.x = src; ta.ldx = sld; ta.norm = raw ? (normalize ? 1 : 0) : 0;   // the tail's slow path re-reads the face's input
     hipLaunchKernelGGL(tail_kernel, dim3((unsigned)(2 * ntiles)), dim3(256), 0, st, ta, (const h8*)in, buf_steps);
   }
   const hipError_t e = hipGetLastError();

@@ -9,7 +9,7 @@
 // with the state (smoothed angles, previous centre, prediction count) kept on the device between
 // frames, so a tick of S streams is one launch and no per-face D2H sync.  A stream whose frame has
 // no face (valid == 0) is skipped exactly like the reference's `continue` (:193-196): its state
-// does not change and its outputs are left untouched.
+// does not change and its outputs are left untouched; so is a stream whose pose is not finite.
 //
 // One thread per stream, all f64 (the reference computes in Python floats).  round(x, 2) is
 // rint(x*100)/100 (half-to-even), which equals Python's correctly-rounded round() except when
@@ -29,6 +29,10 @@ __global__ void video_post_kernel(const float* __restrict__ pose_rad, const floa
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
   if (valid && !valid[s]) return;
+  // A non-finite pose (NaN/Inf landmarks in) is treated like "no face": the stream's state is left alone.  The reference
+  // has no such frame to copy -- its int(x1) at generatePose_on_video.py:121 raises on NaN and ends the loop -- and letting
+  // it through would poison the stream's EMA for good (s = 0.4*NaN + 0.6*s).
+  if (!(isfinite(pose_rad[s * 3 + 0]) && isfinite(pose_rad[s * 3 + 1]) && isfinite(pose_rad[s * 3 + 2]))) return;
   double* st = state + s * 6;               // [sm_yaw, sm_pitch, sm_roll, prev_tdx, prev_tdy, count]
   const double kDeg = 57.29577951308232;    // 180/pi, np.degrees
   double ang[3];

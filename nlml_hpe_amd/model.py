@@ -22,8 +22,8 @@ class HIPPoseModel:
         """mode (int constant or name):
           _lib.MODE_F16X2 "f16x2"  (default) parity mode on the f16 matrix cores: every f32 operand as two f16 pieces,
                                    <= 1e-4 deg of the reference (measured ~1e-5), 2.6x the faces/s of the f32 mode and
-                                   0.17 ms instead of 0.30 ms for a 64-face tick; |activation| must stay below 65504 or
-                                   that face's pose is NaN (never silently wrong);
+                                   0.17 ms instead of 0.30 ms for a 64-face tick; a face whose activations leave f16's
+                                   range is re-evaluated in f32 inside the same launch (no input-range limit);
           _lib.MODE_F32   "f32"    parity mode on the f32 matrix cores (same bar; no range limit; the accumulation is
                                    the k-ordered fmaf chain, bit-identical to the C oracle);
           _lib.MODE_BF16  "bf16"   throughput mode (bf16 weights/activations, ~0.1 deg from the reference -- never a

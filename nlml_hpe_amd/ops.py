@@ -15,8 +15,9 @@ F_REF = 1404
 LATENT = 9
 
 
-def _stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream_ptr(device=None) -> int:
+    """torch's current HIP stream OF `device` (default: the current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def _need_cuda(t: torch.Tensor, name: str, dtype) -> None:
@@ -24,6 +25,28 @@ def _need_cuda(t: torch.Tensor, name: str, dtype) -> None:
         raise _lib.NlmlError(f"{name}: expected a GPU tensor (there is no CPU fallback), got device {t.device}")
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+class _on_device_of:
+    """Every operand on ONE GPU, and the launch on THAT GPU: a HIP launch goes to the calling thread's current device, so a
+    model living on cuda:1 called while cuda:0 is current would run on GPU 0 against GPU 1's memory, on a foreign stream.
+    `with _on_device_of(x, blob, ...) as stream:` checks that all tensors share a device, makes it current for the launch and
+    yields that device's current stream handle; outputs must be allocated on `x.device` by the caller."""
+
+    def __init__(self, *named):
+        ts = [(n, t) for n, t in named if t is not None]
+        self.device = ts[0][1].device
+        for n, t in ts[1:]:
+            if t.device != self.device:
+                raise _lib.NlmlError(f"{n} is on {t.device} but {ts[0][0]} is on {self.device}: all operands must share one GPU")
+        self.guard = torch.cuda.device(self.device)
+
+    def __enter__(self) -> int:
+        self.guard.__enter__()
+        return _stream_ptr(self.device)
+
+    def __exit__(self, *exc):
+        return self.guard.__exit__(*exc)
 
 
 def normalize_ipd(raw: torch.Tensor, normalize: bool = True, return_valid: bool = False):
@@ -35,9 +58,10 @@ def normalize_ipd(raw: torch.Tensor, normalize: bool = True, return_valid: bool 
     B = raw.shape[0]
     out = torch.empty((B, F_REF), dtype=torch.float32, device=raw.device)
     valid = torch.empty((B,), dtype=torch.uint8, device=raw.device) if return_valid else None
-    _lib.check(_lib.lib().nlml_normalize_ipd(raw.data_ptr(), B, int(bool(normalize)), out.data_ptr(),
-                                             valid.data_ptr() if valid is not None else None, _stream_ptr()),
-               "nlml_normalize_ipd")
+    with _on_device_of(("raw", raw)) as stream:
+        _lib.check(_lib.lib().nlml_normalize_ipd(raw.data_ptr(), B, int(bool(normalize)), out.data_ptr(),
+                                                 valid.data_ptr() if valid is not None else None, stream),
+                   "nlml_normalize_ipd")
     return (out, valid.bool()) if return_valid else out
 
 
@@ -55,10 +79,11 @@ def encoder_heads_fwd(x: torch.Tensor, blob: torch.Tensor, F: int, return_latent
     out = torch.empty((B, 3), dtype=torch.float32, device=x.device)
     latent = torch.empty((B, LATENT), dtype=torch.float32, device=x.device) if return_latent else None
     valid = torch.empty((B,), dtype=torch.uint8, device=x.device) if return_valid else None
-    _lib.check(_lib.lib().nlml_encoder_heads_fwd(
-        x.data_ptr(), ldx, B, F, blob.data_ptr(), blob.numel(), out.data_ptr(),
-        latent.data_ptr() if latent is not None else None,
-        valid.data_ptr() if valid is not None else None, _stream_ptr()), "nlml_encoder_heads_fwd")
+    with _on_device_of(("x", x), ("blob", blob)) as stream:
+        _lib.check(_lib.lib().nlml_encoder_heads_fwd(
+            x.data_ptr(), ldx, B, F, blob.data_ptr(), blob.numel(), out.data_ptr(),
+            latent.data_ptr() if latent is not None else None,
+            valid.data_ptr() if valid is not None else None, stream), "nlml_encoder_heads_fwd")
     res = [out]
     if return_latent:
         res.append(latent)
@@ -79,10 +104,11 @@ def encoder_heads_fwd_debug(x: torch.Tensor, blob: torch.Tensor, F: int, want_st
     latent = torch.empty((B, LATENT), dtype=torch.float32, device=x.device)
     pre = torch.empty((B, 64), dtype=torch.float32, device=x.device)
     stamps = torch.zeros(((B + 63) // 64, 4, 16), dtype=torch.int64, device=x.device) if want_stamps else None
-    _lib.check(_lib.lib().nlml_encoder_heads_fwd_debug(x.data_ptr(), F, B, F, blob.data_ptr(), blob.numel(),
-                                                       out.data_ptr(), latent.data_ptr(), pre.data_ptr(),
-                                                       stamps.data_ptr() if want_stamps else None, _stream_ptr()),
-               "nlml_encoder_heads_fwd_debug")
+    with _on_device_of(("x", x), ("blob", blob)) as stream:
+        _lib.check(_lib.lib().nlml_encoder_heads_fwd_debug(x.data_ptr(), F, B, F, blob.data_ptr(), blob.numel(),
+                                                           out.data_ptr(), latent.data_ptr(), pre.data_ptr(),
+                                                           stamps.data_ptr() if want_stamps else None, stream),
+                   "nlml_encoder_heads_fwd_debug")
     return (out, latent, pre, stamps) if want_stamps else (out, latent, pre)
 
 
@@ -98,10 +124,11 @@ def landmarks_to_pose(raw: torch.Tensor, blob: torch.Tensor, normalize: bool = T
     out = torch.empty((B, 3), dtype=torch.float32, device=raw.device)
     latent = torch.empty((B, LATENT), dtype=torch.float32, device=raw.device) if return_latent else None
     valid = torch.empty((B,), dtype=torch.uint8, device=raw.device) if return_valid else None
-    _lib.check(_lib.lib().nlml_landmarks_to_pose(
-        raw.data_ptr(), B, int(bool(normalize)), blob.data_ptr(), blob.numel(), out.data_ptr(),
-        latent.data_ptr() if latent is not None else None,
-        valid.data_ptr() if valid is not None else None, _stream_ptr()), "nlml_landmarks_to_pose")
+    with _on_device_of(("raw", raw), ("blob", blob)) as stream:
+        _lib.check(_lib.lib().nlml_landmarks_to_pose(
+            raw.data_ptr(), B, int(bool(normalize)), blob.data_ptr(), blob.numel(), out.data_ptr(),
+            latent.data_ptr() if latent is not None else None,
+            valid.data_ptr() if valid is not None else None, stream), "nlml_landmarks_to_pose")
     res = [out]
     if return_latent:
         res.append(latent)
@@ -139,10 +166,11 @@ def tucker_objective(Wm: torch.Tensor, x: torch.Tensor, params: torch.Tensor, co
         raise ValueError(f"x has {x.shape[0]} rows but params has {N} (pass x_index to share rows)")
     err = torch.empty((N,), dtype=torch.float64, device=x.device)
     xh = torch.empty((N, F_REF), dtype=torch.float64, device=x.device) if return_xhat else None
-    _lib.check(_lib.lib().nlml_tucker_objective(
-        Wm.data_ptr(), x.data_ptr(), F_REF, x_index.data_ptr() if x_index is not None else None,
-        params.data_ptr(), cos_params.data_ptr(), N, err.data_ptr(),
-        xh.data_ptr() if xh is not None else None, _stream_ptr()), "nlml_tucker_objective")
+    with _on_device_of(("x", x), ("Wm", Wm), ("params", params), ("cos_params", cos_params), ("x_index", x_index)) as stream:
+        _lib.check(_lib.lib().nlml_tucker_objective(
+            Wm.data_ptr(), x.data_ptr(), F_REF, x_index.data_ptr() if x_index is not None else None,
+            params.data_ptr(), cos_params.data_ptr(), N, err.data_ptr(),
+            xh.data_ptr() if xh is not None else None, stream), "nlml_tucker_objective")
     return (err, xh) if return_xhat else err
 
 
@@ -220,10 +248,11 @@ def tucker_powell(Wm: torch.Tensor, x: torch.Tensor, cos_params: torch.Tensor, x
     nfev = torch.empty((N,), dtype=torch.int32, device=dev)
     nit = torch.empty((N,), dtype=torch.int32, device=dev)
     status = torch.empty((N,), dtype=torch.int32, device=dev)
-    _lib.check(_lib.lib().nlml_tucker_powell(Wm.data_ptr(), x.data_ptr(), F_REF, cos_params.data_ptr(), N,
-                                             x0.data_ptr() if x0 is not None else None, res.data_ptr(), fun.data_ptr(),
-                                             nfev.data_ptr(), nit.data_ptr(), status.data_ptr(), _stream_ptr()),
-               "nlml_tucker_powell")
+    with _on_device_of(("x", x), ("Wm", Wm), ("cos_params", cos_params), ("x0", x0)) as stream:
+        _lib.check(_lib.lib().nlml_tucker_powell(Wm.data_ptr(), x.data_ptr(), F_REF, cos_params.data_ptr(), N,
+                                                 x0.data_ptr() if x0 is not None else None, res.data_ptr(), fun.data_ptr(),
+                                                 nfev.data_ptr(), nit.data_ptr(), status.data_ptr(), stream),
+                   "nlml_tucker_powell")
     return {"x": res, "fun": fun, "nfev": nfev, "nit": nit, "status": status}
 
 
@@ -238,8 +267,9 @@ def cosine_table(angles_rad: torch.Tensor, cos_params: torch.Tensor) -> torch.Te
     angles_rad, cos_params = angles_rad.contiguous(), cos_params.contiguous()
     n, R = angles_rad.shape[0], cos_params.shape[0]
     out = torch.empty((n, R), dtype=torch.float64, device=angles_rad.device)
-    _lib.check(_lib.lib().nlml_cosine_table(angles_rad.data_ptr(), n, cos_params.data_ptr(), R, out.data_ptr(), _stream_ptr()),
-               "nlml_cosine_table")
+    with _on_device_of(("angles_rad", angles_rad), ("cos_params", cos_params)) as stream:
+        _lib.check(_lib.lib().nlml_cosine_table(angles_rad.data_ptr(), n, cos_params.data_ptr(), R, out.data_ptr(), stream),
+                   "nlml_cosine_table")
     return out
 
 
@@ -254,8 +284,9 @@ def mode5_product(core: torch.Tensor, U_feat: torch.Tensor) -> torch.Tensor:
     U_feat = U_feat.contiguous()
     Q, R5, M = c2.shape[0], c2.shape[1], U_feat.shape[0]
     W = torch.empty((Q, M), dtype=torch.float32, device=core.device)
-    _lib.check(_lib.lib().nlml_mode5_product(c2.data_ptr(), U_feat.data_ptr(), Q, R5, M, W.data_ptr(), _stream_ptr()),
-               "nlml_mode5_product")
+    with _on_device_of(("core", core), ("U_feat", U_feat)) as stream:
+        _lib.check(_lib.lib().nlml_mode5_product(c2.data_ptr(), U_feat.data_ptr(), Q, R5, M, W.data_ptr(), stream),
+                   "nlml_mode5_product")
     return W.reshape(lead + (M,))
 
 
@@ -268,7 +299,7 @@ def _small_workspace(B: int, F: int, device) -> torch.Tensor:
     adding a larger buffer next to the old one.  The first one is sized for 4,096 faces of the reference width (46 MB)."""
     need = _lib.lib().nlml_encoder_heads_small_workspace_bytes(B, F)
     # one pool per (device, stream): launches on different streams may overlap and must not share scratch
-    pool = _small_ws.setdefault((str(device), _stream_ptr()), [])
+    pool = _small_ws.setdefault((str(device), _stream_ptr(device)), [])
     for ws in pool:
         if ws.numel() >= need:
             return ws
@@ -293,11 +324,12 @@ def encoder_heads_fwd_small(x: torch.Tensor, blob: torch.Tensor, F: int, return_
     out = torch.empty((B, 3), dtype=torch.float32, device=x.device)
     latent = torch.empty((B, LATENT), dtype=torch.float32, device=x.device) if return_latent else None
     valid = torch.empty((B,), dtype=torch.uint8, device=x.device) if return_valid else None
-    _lib.check(_lib.lib().nlml_encoder_heads_fwd_small(
-        x.data_ptr(), ldx, B, F, blob.data_ptr(), blob.numel(), out.data_ptr(),
-        latent.data_ptr() if latent is not None else None,
-        valid.data_ptr() if valid is not None else None, ws.data_ptr(), ws.numel(), _stream_ptr()),
-        "nlml_encoder_heads_fwd_small")
+    with _on_device_of(("x", x), ("blob", blob), ("workspace", ws)) as stream:
+        _lib.check(_lib.lib().nlml_encoder_heads_fwd_small(
+            x.data_ptr(), ldx, B, F, blob.data_ptr(), blob.numel(), out.data_ptr(),
+            latent.data_ptr() if latent is not None else None,
+            valid.data_ptr() if valid is not None else None, ws.data_ptr(), ws.numel(), stream),
+            "nlml_encoder_heads_fwd_small")
     res = [out]
     if return_latent:
         res.append(latent)
@@ -319,11 +351,12 @@ def landmarks_to_pose_small(raw: torch.Tensor, blob: torch.Tensor, normalize: bo
     out = torch.empty((B, 3), dtype=torch.float32, device=raw.device)
     latent = torch.empty((B, LATENT), dtype=torch.float32, device=raw.device) if return_latent else None
     valid = torch.empty((B,), dtype=torch.uint8, device=raw.device) if return_valid else None
-    _lib.check(_lib.lib().nlml_landmarks_to_pose_small(
-        raw.data_ptr(), B, int(bool(normalize)), blob.data_ptr(), blob.numel(), out.data_ptr(),
-        latent.data_ptr() if latent is not None else None,
-        valid.data_ptr() if valid is not None else None, ws.data_ptr(), ws.numel(), _stream_ptr()),
-        "nlml_landmarks_to_pose_small")
+    with _on_device_of(("raw", raw), ("blob", blob), ("workspace", ws)) as stream:
+        _lib.check(_lib.lib().nlml_landmarks_to_pose_small(
+            raw.data_ptr(), B, int(bool(normalize)), blob.data_ptr(), blob.numel(), out.data_ptr(),
+            latent.data_ptr() if latent is not None else None,
+            valid.data_ptr() if valid is not None else None, ws.data_ptr(), ws.numel(), stream),
+            "nlml_landmarks_to_pose_small")
     res = [out]
     if return_latent:
         res.append(latent)

@@ -38,11 +38,13 @@ class VideoPoseTracker:
             if tuple(valid.shape) != (self.S,):
                 raise ValueError("valid: expected [S]")
             v8 = valid.to(torch.uint8).contiguous()
-        _lib.check(_lib.lib().nlml_video_post(
-            pose_rad.contiguous().data_ptr(), raw.contiguous().data_ptr(), v8.data_ptr() if v8 is not None else None,
-            self.S, self.frame_w, self.frame_h, self.alpha, self.max_jump, self.size, self.state.data_ptr(),
-            self.smoothed.data_ptr(), self.centre.data_ptr(), self.endpoints.data_ptr(), ops._stream_ptr()),
-            "nlml_video_post")
+        pose_rad, raw = pose_rad.contiguous(), raw.contiguous()
+        with ops._on_device_of(("state", self.state), ("pose_rad", pose_rad), ("raw", raw), ("valid", v8)) as stream:
+            _lib.check(_lib.lib().nlml_video_post(
+                pose_rad.data_ptr(), raw.data_ptr(), v8.data_ptr() if v8 is not None else None,
+                self.S, self.frame_w, self.frame_h, self.alpha, self.max_jump, self.size, self.state.data_ptr(),
+                self.smoothed.data_ptr(), self.centre.data_ptr(), self.endpoints.data_ptr(), stream),
+                "nlml_video_post")
         return self.smoothed, self.centre, self.endpoints
 
     def tick(self, raw: torch.Tensor):
@@ -63,20 +65,22 @@ class GraphedTick:
     def __init__(self, tracker: VideoPoseTracker):
         self.tracker = tracker
         dev = tracker.model.device
-        self.static_raw = torch.zeros((tracker.S, 468, 3), dtype=torch.float32, device=dev)
-        saved = tracker.state.clone()
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                  # warm-up outside capture
-            for _ in range(2):
-                tracker.tick(self.static_raw)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        tracker.state.copy_(saved)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.outputs = tracker.tick(self.static_raw)
-        tracker.state.copy_(saved)                     # the capture itself does not execute the tick
+        with torch.cuda.device(dev):                       # capture on the model's GPU, whatever the caller's current device
+            self.static_raw = torch.zeros((tracker.S, 468, 3), dtype=torch.float32, device=dev)
+            saved = tracker.state.clone()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                  # warm-up outside capture
+                for _ in range(2):
+                    tracker.tick(self.static_raw)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            tracker.state.copy_(saved)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.outputs = tracker.tick(self.static_raw)
+            tracker.state.copy_(saved)                     # the capture itself does not execute the tick
 
     def replay(self):
-        self.graph.replay()
+        with torch.cuda.device(self.tracker.model.device):
+            self.graph.replay()
         return self.outputs

@@ -597,9 +597,10 @@ def test_split_f16_full_batch_65536_properties(head_sds, device):
     assert torch.equal(ops.encoder_heads_fwd(xt[:B - 1], blob, F), full[:B - 1])
 
 
-def test_split_f16_nan_inf_and_f16_overflow_are_loud(head_sds, device):
-    """NaN/Inf stay in their face; an activation beyond f16's range (|x| >= 65520) makes THAT face's pose NaN -- never a
-    silently wrong number -- and leaves the other faces of the tile untouched."""
+def test_split_f16_nan_inf_stay_loud_and_f16_overflow_is_rescued(head_sds, device):
+    """NaN/Inf inputs stay in their face (non-finite pose, as in the reference).  A FINITE input whose activations leave f16's
+    range (|v| >= 65520) is re-evaluated by the kernel's f32 slow path (encoder_heads_f16x2_rescue.h): finite, accurate, and
+    the other faces of the tile keep their bits."""
     F = 1404
     sd = synth.encoder_state_dict(F, seed=0)
     blob = _blob_hx(sd, head_sds, device)
@@ -609,18 +610,61 @@ def test_split_f16_nan_inf_and_f16_overflow_are_loud(head_sds, device):
     bad[5, 100] = np.nan
     bad[70, 1403] = np.inf
     bad[133, 0] = -np.inf
-    bad[150, 7] = 7.0e4               # finite in f32, beyond f16
-    bad[151, 7] = 6.0e4               # still inside f16: must stay finite and accurate
-    out = ops.encoder_heads_fwd(torch.from_numpy(bad).to(device), blob, F)
+    bad[150, 7] = 7.0e4               # finite in f32, beyond f16: slow path
+    bad[151, 7] = 6.0e4               # still inside f16: fast path, must stay accurate
+    bad[152] *= 3.0e4                 # overflow in the hidden layers too
+    bad[199] = -2.5e5                 # last face of a partial tile
+    out, lat = ops.encoder_heads_fwd(torch.from_numpy(bad).to(device), blob, F, return_latent=True)
     rows = torch.ones(200, dtype=torch.bool, device=device)
-    rows[[5, 70, 133, 150, 151]] = False
+    rows[[5, 70, 133, 150, 151, 152, 199]] = False
     assert torch.equal(out[rows], clean[rows])
-    for r in (5, 70, 133, 150):
-        assert torch.isnan(out[r]).all() or not torch.isfinite(out[r]).all(), r
-    assert torch.isnan(out[150]).all()
-    ref = EH.forward_numpy(bad[151:152], EH.Params(sd, head_sds), np.float64)
-    rel = np.abs(out[151].cpu().numpy() - ref[0]) / np.maximum(1.0, np.abs(ref[0]))
-    assert torch.isfinite(out[151]).all() and rel.max() <= 1e-5
+    for r in (5, 70, 133):
+        assert not torch.isfinite(out[r]).all(), r
+    P = EH.Params(sd, head_sds)
+    for r in (150, 151, 152, 199):
+        ref = EH.forward_numpy(bad[r:r + 1], P, np.float64)
+        ref32 = EH.forward_torch(bad[r:r + 1], P)
+        e = np.degrees(np.abs(out[r].cpu().numpy() - ref[0]).max())
+        _report(f"split_f16_rescue_row{r}", max_abs_deg=e, torch_f32_vs_f64_deg=np.degrees(np.abs(np.asarray(ref32) - ref).max()))
+        assert torch.isfinite(out[r]).all() and e <= POSE_TOL_DEG, (r, e)
+        assert np.abs(lat[r].cpu().numpy() - EH.encoder_latent_numpy(bad[r:r + 1], P, np.float64)[0]).max() <= 5e-6
+    # the layer-per-launch path takes the same slow path: identical bits
+    out_s = ops.encoder_heads_fwd_small(torch.from_numpy(bad).to(device), blob, F)
+    fin = torch.isfinite(out).all(dim=1)
+    assert torch.equal(out_s[fin], out[fin]) and torch.equal(torch.isfinite(out_s).all(dim=1), fin)
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "f32"])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_fx1_degenerate_faces_through_the_fused_path(mode, normalize, head_sds, golden_dir, device):
+    """FX1's faces -- ipd == 0 (the reference's 1e-6 branch, FeatureExtractor.py:47-48: features ~1e6), near-degenerate ipd,
+    a tiny face, pixel-scale coordinates -- from raw landmarks to pose in ONE launch, both parity modes: finite, and within
+    1e-4 deg of the f64 oracle on the reference's own feature rows (the fixture).  One stated exception: the un-normalised
+    pixel-scale face (features to 1.9e3, |pre-tanh| ~ 1e2) where the reference's own f32 forward is 1.2e-4 deg off the truth."""
+    from nlml_hpe_amd import _lib
+    g = np.load(os.path.join(golden_dir, "fx1_normalise.npz"))
+    sd = synth.encoder_state_dict(1404, seed=0)
+    blob = torch.from_numpy(weights.pack_blob(sd, head_sds, _lib.mode_from_name(mode))).to(device)
+    raw = torch.from_numpy(g["landmarks"]).to(device)
+    feats = g["features_norm" if normalize else "features_raw"]
+    P = EH.Params(sd, head_sds)
+    truth = EH.forward_numpy(feats, P, np.float64)
+    ref32 = np.asarray(EH.forward_torch(feats, P, num_threads=1))
+    pose, valid = ops.landmarks_to_pose(raw, blob, normalize, return_valid=True)
+    pose = pose.cpu().numpy()
+    assert np.isfinite(pose).all() and valid.all()
+    err = np.degrees(np.abs(pose - truth).max(1))
+    tol = np.full(16, POSE_TOL_DEG)
+    if not normalize:
+        tol[5] = 5e-4
+    _report(f"fx1_fused_{mode}_norm{int(normalize)}", max_abs_deg=err.max(), max_abs_deg_wo_face5=np.delete(err, 5).max(),
+            torch_f32_vs_f64_deg=np.degrees(np.abs(ref32 - truth).max()))
+    assert (err <= tol).all(), err
+    if mode == "f16x2":
+        small = ops.landmarks_to_pose_small(raw, blob, normalize)
+        assert torch.equal(small, torch.from_numpy(pose).to(device))
+        two_step = ops.encoder_heads_fwd(torch.from_numpy(feats).to(device), blob, 1404)
+        assert torch.equal(two_step, torch.from_numpy(pose).to(device))     # fused == K1 -> K2, slow-path faces included
 
 
 def test_split_f16_strided_unaligned_input_and_determinism(head_sds, device):
@@ -858,3 +902,44 @@ def test_fx2b_heads_operating_points_golden(mode, head_sds, golden_dir, device):
     if mode == "f16x2":
         small = ops.encoder_heads_fwd_small(torch.from_numpy(x).to(device), blob, 136)
         assert torch.equal(small, out)
+
+
+def test_video_post_skips_non_finite_pose(head_sds, device):
+    """A stream whose pose is NaN/Inf in one tick keeps its EMA state (like a no-face frame) instead of being poisoned for good."""
+    from nlml_hpe_amd.model import HIPPoseModel
+    from nlml_hpe_amd.video import VideoPoseTracker
+    mdl = HIPPoseModel(synth.encoder_state_dict(1404, seed=0), head_sds, device=device)
+    S = 8
+    tr = VideoPoseTracker(mdl, S, 1920, 1080)
+    raw = torch.from_numpy(synth.raw_landmarks(S, seed=31)).to(device)
+    pose = mdl.from_landmarks(raw)
+    tr.post(pose, raw)
+    before = tr.state.clone()
+    bad = pose.clone()
+    bad[2, 1] = float("nan")
+    bad[5, 0] = float("inf")
+    tr.post(bad, raw)
+    after = tr.state
+    assert torch.equal(after[[2, 5]], before[[2, 5]])                     # untouched, count not advanced
+    ok = [0, 1, 3, 4, 6, 7]
+    assert torch.isfinite(after).all() and (after[ok, 5] == 2).all()
+    tr.post(pose, raw)                                                    # and the stream goes on
+    assert (tr.state[[2, 5], 5] == 2).all() and torch.isfinite(tr.smoothed).all()
+
+
+def test_ops_follow_the_tensors_device(head_sds):
+    """a model on a GPU that is not the current one must launch THERE (device guard + that device's stream), and
+    operands on different GPUs are refused.  Needs two GPUs; the one-GPU box skips it."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    from nlml_hpe_amd import _lib
+    sd = synth.encoder_state_dict(136, seed=0)
+    x = synth.features(100, 136, seed=2)
+    d0, d1 = torch.device("cuda:0"), torch.device("cuda:1")
+    blob0, blob1 = _blob_hx(sd, head_sds, d0), _blob_hx(sd, head_sds, d1)
+    torch.cuda.set_device(0)
+    out1 = ops.encoder_heads_fwd(torch.from_numpy(x).to(d1), blob1, 136)       # current device 0, operands on 1
+    out0 = ops.encoder_heads_fwd(torch.from_numpy(x).to(d0), blob0, 136)
+    assert out1.device == d1 and torch.equal(out1.cpu(), out0.cpu())
+    with pytest.raises(_lib.NlmlError):
+        ops.encoder_heads_fwd(torch.from_numpy(x).to(d0), blob1, 136)
