@@ -46,7 +46,7 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
                                               f32x16 (&acc)[4][2]) {
   constexpr int NB = 4, NFB = 2;
   const int F = a.F;
-  const int nslab = (int)c.hdr->k8_e0 / XS_STEPS;   // even (pack.cpp)
+  const int nslab = (int)c.hdr.k8_e0 / XS_STEPS;   // even (pack.cpp)
   constexpr int SLAB_BYTES = 2 * P_XS;
 
   // staging role: row srow (0..63), 8 consecutive columns scol..scol+7 of every slab
@@ -73,78 +73,72 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
   }
   unsigned nzbits = 0u;
 
-  auto gload = [&](int s, f32x4 (&st)[2]) {
+  // staging set: 8 consecutive columns of one row as scalars (each piece below touches single elements)
+  struct Set { float v[8]; };
+  auto gload_half = [&](int s, Set& st, int i) {   // columns scol + 4i .. + 3 of slab s
     s = s < nslab ? s : nslab - 1;
+    const int k = s * XS_COLS + scol + 4 * i;
+    if (VEC4) {
+      const int kc = k < F ? k : (NORM ? k - 12 * ((k - F + 15) / 12) : F - 4);   // phase-preserving clamp
+      const f32x4 t = *reinterpret_cast<const f32x4*>(p + kc);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int k = s * XS_COLS + scol + 4 * i;
-      if (VEC4) {
-        const int kc = k < F ? k : (NORM ? k - 12 * ((k - F + 15) / 12) : F - 4);   // phase-preserving clamp
-        st[i] = *reinterpret_cast<const f32x4*>(p + kc);
-      } else {
+      for (int e = 0; e < 4; ++e) st.v[4 * i + e] = t[e];
+    } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) st[i][e] = p[k + e < F ? k + e : F - 1];
-      }
+      for (int e = 0; e < 4; ++e) st.v[4 * i + e] = p[k + e < F ? k + e : F - 1];
     }
   };
-  // staging of one slab in pieces (one per MFMA gap of the slab's first K step; lwrite() = all of them, prologue)
-  auto lw_begin = [&](f32x4 (&st)[2]) {   // the set's loads must have landed: everything below consumes them
+  auto gload = [&](int s, Set& st) { gload_half(s, st, 0); gload_half(s, st, 1); };
+  // staging of one slab in pieces, one per free MFMA slot of the slab's two K steps (lwrite() = all of them, prologue)
+  auto lw_begin = [&](Set& st) {   // the set's loads must have landed: everything below consumes them
 #pragma unroll
-    for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(st[i]));
+    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(st.v[e]));
   };
-  auto lw_norm = [&](f32x4 (&st)[2], int j) {   // elements 2j, 2j+1 (j static)
-#pragma unroll
-    for (int q = 2 * j; q < 2 * j + 2; ++q) {
-      const int t = q % 3;
-      const double rr = t == 0 ? ra : (t == 1 ? rb : rc);
-      st[q / 4][q % 4] = (float)div_ipd((double)st[q / 4][q % 4] - rr, ipd, rcp);
-    }
+  auto lw_norm = [&](Set& st, int q) {   // element q (static)
+    const int t = q % 3;
+    const double rr = t == 0 ? ra : (t == 1 ? rb : rc);
+    st.v[q] = (float)div_ipd((double)st.v[q] - rr, ipd, rcp);
   };
   auto lw_rotate = [&]() {   // next slab: columns + 32 => phase + 2
     const double t0 = rc; rc = rb; rb = ra; ra = t0;
   };
-  h8 pend_hi, pend_lo;
-  auto lw_split = [&](f32x4 (&st)[2], int i, bool real_slab) {   // half i of the 8 elements -> hi/lo f16
-    // the f32 value must exist as such: without this fence hipcc 7.2 folds (f16)(f32)double into ONE f64 -> f16
-    // conversion, done in ~20 integer instructions per element and rounded differently from the two-step path
-    asm volatile("" : "+v"(st[i]));
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  unsigned pend_hi[4], pend_lo[4];
+  auto lw_split = [&](Set& st, int j, bool real_slab) {   // elements 2j, 2j+1 -> packed hi/lo f16 pairs
     const unsigned m = real_slab ? 0x7fffffffu : 0u;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float v = st[i][e];
-      nzbits |= __float_as_uint(v) & m;
-      const _Float16 hv = (_Float16)v;
-      pend_hi[4 * i + e] = hv;
-      pend_lo[4 * i + e] = (_Float16)(v - (float)hv);
-    }
+    // split2 takes the f32 VALUES (asm operands), so the compiler cannot fold (f16)(f32)double into one f64 -> f16 conversion
+    // as hipcc 7.2 does for the C form (~20 integer instructions per element and a different rounding)
+    nzbits |= (__float_as_uint(st.v[2 * j]) | __float_as_uint(st.v[2 * j + 1])) & m;
+    split2(st.v[2 * j], st.v[2 * j + 1], pend_hi[j], pend_lo[j]);
   };
-  auto lw_store = [&](int buf_off) {
+  auto lw_store = [&](int buf_off, int piece) {
     char* d = c.lds + O_XS + buf_off + (srow * S_XS + scol) * 2;
-    *reinterpret_cast<h8*>(d) = pend_hi;
-    *reinterpret_cast<h8*>(d + P_XS) = pend_lo;
+    if (piece == 0) *reinterpret_cast<u4*>(d) = u4{pend_hi[0], pend_hi[1], pend_hi[2], pend_hi[3]};
+    else *reinterpret_cast<u4*>(d + P_XS) = u4{pend_lo[0], pend_lo[1], pend_lo[2], pend_lo[3]};
   };
-  auto lwrite = [&](int buf_off, f32x4 (&st)[2], bool real_slab) {
+  auto lwrite = [&](int buf_off, Set& st, bool real_slab) {
     lw_begin(st);
     if (NORM) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) lw_norm(st, j);
+      for (int q = 0; q < 8; ++q) lw_norm(st, q);
       lw_rotate();
     }
-    lw_split(st, 0, real_slab);
-    lw_split(st, 1, real_slab);
-    lw_store(buf_off);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lw_split(st, j, real_slab);
+    lw_store(buf_off, 0);
+    lw_store(buf_off, 1);
   };
 
   const int job = 4 * pass + c.wv;
-  load_bias<NB, NFB>(acc, c.blob4 + c.hdr->b_off[ST_E0] + job * (NB * 8), c.h);
-  const h8* w = c.blob8 + c.hdr->w_off[ST_E0] + (size_t)job * c.hdr->job_w16[ST_E0] + c.lane;
+  load_bias<NB, NFB>(acc, c.blob4 + c.hdr.b_off(ST_E0) + job * (NB * 8), c.h);
+  const h8* w = c.blob8 + c.hdr.w_off(ST_E0) + (size_t)job * c.hdr.job_w16(ST_E0) + c.lane;
 
-  // TWO staging register sets (8 floats per thread each), one per slab parity: slab s+2 is written to LDS at the
-  // start of slab s from set[s & 1], which is refilled at once with the loads of slab s+4.  vmcnt counts in issue
+  // TWO staging register sets (8 floats per thread each), one per slab parity: slab s+2 is written to LDS during
+  // slab s from set[s & 1], which is refilled at once with the loads of slab s+4.  vmcnt counts in issue
   // order, so a set must be older than every weight load still wanted in flight when it is waited for: two slabs
   // (4 K steps, 32 weight loads) lie between its loads and its use, and in the prologue the sets are loaded BEFORE
   // the weight ring so that the loop header sees the same distance on entry as on the back edge.
-  f32x4 set[2][2];
+  Set set[2];
   constexpr int R0 = 4, D0 = R0 - 1;   // weight ring: K step ks in slot ks % 4 = 2*(slab & 1) + step of the slab
   static_assert(2 * XS_STEPS == R0, "two slabs == ring slots");
   h8 wr[R0][NB][2];
@@ -179,24 +173,26 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
 #pragma unroll
     for (int kk = 0; kk < XS_STEPS; ++kk) {
       const int slot = 2 * PAR + kk;
-      step_il(acc, wr[slot], xr[kk & 1], wr[(slot + D0) % R0], w + (size_t)(s * XS_STEPS + kk + D0) * (NB * 2 * 64),
-              [&]() {
-#pragma unroll
-                for (int fb = 0; fb < NFB; ++fb)
-#pragma unroll
-                  for (int pp = 0; pp < 2; ++pp)
-                    xr[(kk + 1) & 1][fb][pp] = (kk + 1 < XS_STEPS)
-                                                   ? *reinterpret_cast<const h8*>(xrow + pp * P_XS + fb * FB + 32 * (kk + 1))
-                                                   : *reinterpret_cast<const h8*>(xnext + pp * P_XS + fb * FB);
+      step_fine<NB, NFB>(acc, wr[slot], xr[kk & 1], wr[(slot + D0) % R0], w + (size_t)(s * XS_STEPS + kk + D0) * (NB * 2 * 64), true,
+              [&](int fb, int pp) {
+                xr[(kk + 1) & 1][fb][pp] = (kk + 1 < XS_STEPS)
+                                               ? *reinterpret_cast<const h8*>(xrow + pp * P_XS + fb * FB + 32 * (kk + 1))
+                                               : *reinterpret_cast<const h8*>(xnext + pp * P_XS + fb * FB);
               },
-              [&](int g) {   // slab s+2's staging, one piece per gap: step 0 normalises, step 1 splits, stores, reloads
-                if (kk == 0 && g == 0) lw_begin(set[PAR]);
-                if (NORM && kk == 0 && g >= 1 && g <= 4) lw_norm(set[PAR], g - 1);
-                if (NORM && kk == 0 && g == 5) lw_rotate();
-                if (kk == 1 && g == 0) lw_split(set[PAR], 0, real);
-                if (kk == 1 && g == 1) lw_split(set[PAR], 1, real);
-                if (kk == 1 && g == 2) lw_store(o2);
-                if (kk == 1 && g == 3) gload(s + 4, set[PAR]);
+              [&](int m) {   // slab s+2's staging in the step's free (odd) slots: step 0 normalises, step 1 splits, stores, reloads
+                if ((m & 1) == 0) return;
+                const int j = m >> 1;                        // free slot 0..11 of this step
+                if (kk == 0) {
+                  if (j == 0) lw_begin(set[PAR]);
+                  if (NORM && j >= 1 && j <= 8) lw_norm(set[PAR], j - 1);
+                  if (NORM && j == 9) lw_rotate();
+                } else {
+                  if (j < 4) lw_split(set[PAR], j, real);
+                  if (j == 4) lw_store(o2, 0);
+                  if (j == 5) lw_store(o2, 1);
+                  if (j == 6) gload_half(s + 4, set[PAR], 0);
+                  if (j == 7) gload_half(s + 4, set[PAR], 1);
+                }
               });
     }
     __syncthreads();
@@ -222,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
   Ctx c;
   c.blob8 = reinterpret_cast<const h8*>(a.blob);
   c.blob4 = reinterpret_cast<const f32x4*>(a.blob);
-  c.hdr = reinterpret_cast<const Header*>(a.blob);
+  c.hdr = load_hdr(reinterpret_cast<const Header*>(a.blob));
   c.lds = lds;
   c.lane = tid & 63;
   c.f = c.lane & 31;
@@ -231,11 +227,13 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
   const int wv = c.wv;
   const int64_t row0 = (int64_t)blockIdx.x * TILE_FACES;
 
+  f32x16 acc2[2][2];
+  h8 wr2[ring_slots(2, 2)][2][2];
   {  // E0 (two passes of 512 neurons) interleaved with the two K halves of E1
     f32x16 acc1[4][2];
-    load_bias<4, 2>(acc1, c.blob4 + c.hdr->b_off[ST_E1] + wv * (4 * 8), c.h);
-    const h8* w1 = c.blob8 + c.hdr->w_off[ST_E1] + (size_t)wv * c.hdr->job_w16[ST_E1] + c.lane;
-    const float inv0 = c.hdr->inv_scale[ST_E0];
+    load_bias<4, 2>(acc1, c.blob4 + c.hdr.b_off(ST_E1) + wv * (4 * 8), c.h);
+    const h8* w1 = c.blob8 + c.hdr.w_off(ST_E1) + (size_t)wv * c.hdr.job_w16(ST_E1) + c.lane;
+    const float inv0 = c.hdr.inv_scale[ST_E0];
     HXS(0);
     HXS_WALL(30);
 #pragma unroll 1
@@ -255,19 +253,22 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
       __syncthreads();   // H1H is free again (pass 0: for pass 1's store; pass 1: for H2)
       HXS(4 + 4 * pass);
     }
-    job_store<4, 2, ACT_RELU>(c, acc1, O_H2, P_H2, S_H2, 128 * wv, 0, c.hdr->inv_scale[ST_E1]);
+    // E2's global fetches (bias, first ring slots) ride in E1's epilogue (store_lds hook, encoder_heads_f16x2_dev.h)
+    job_store<4, 2, ACT_RELU>(c, acc1, O_H2, P_H2, S_H2, 128 * wv, 0, c.hdr.inv_scale[ST_E1],
+                              fetch_hook<16, 2, 2, ST_E2>(c, wv, acc2, wr2));
   }
   __syncthreads();
   HXS(9);
-  {  // E2: 512 -> 256, ReLU; h3 overwrites h2 => barrier between the K loop and the store
-    f32x16 acc[2][2];
-    job_compute<2, 2, ST_E2>(c, wv, acc, O_H2, P_H2, S_H2, 0, 0);
-    __syncthreads();
-    job_store<2, 2, ACT_RELU>(c, acc, O_H3, P_H3, S_H3, 64 * wv, 0, c.hdr->inv_scale[ST_E2]);
-  }
+  f32x16 acc3[1][2];
+  h8 wr3[ring_slots(1, 2)][1][2];
+  // E2: 512 -> 256, ReLU; h3 overwrites h2 => barrier between the K loop and the store
+  job_run<2, 2, ST_E2>(c, wv, acc2, wr2, O_H2, P_H2, S_H2, 0, 0);
+  __syncthreads();
+  job_store<2, 2, ACT_RELU>(c, acc2, O_H3, P_H3, S_H3, 64 * wv, 0, c.hdr.inv_scale[ST_E2],
+                            fetch_hook<8, 1, 2, ST_E3>(c, wv, acc3, wr3));
   __syncthreads();
   HXS(10);
-  tail_stages(c, a, row0);
+  tail_stages<false>(c, a, row0, acc3, wr3);
   HXS_WALL(31);
 }
 

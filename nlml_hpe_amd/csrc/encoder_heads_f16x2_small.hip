@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(hx::Args a, const h8* __re
   hx::Ctx c;
   c.blob8 = reinterpret_cast<const h8*>(a.blob);
   c.blob4 = reinterpret_cast<const f32x4*>(a.blob);
-  c.hdr = reinterpret_cast<const Header*>(a.blob);
+  c.hdr = hx::load_hdr(reinterpret_cast<const Header*>(a.blob));
   c.lds = lds;
   c.lane = tid & 63;
   c.f = c.lane & 31;
@@ -227,6 +227,9 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(hx::Args a, const h8* __re
   const int64_t tile = blockIdx.x >> 1, row0 = tile * TILE_FACES;
   const int fbsel = blockIdx.x & 1;
   if (row0 + 32 * fbsel >= a.B) return;                       // no live face in this block (whole workgroup leaves)
+  f32x16 acc3[1][1];
+  h8 wr3[hx::ring_slots(1, 1)][1][2];
+  hx::tail_pre_e3<true>(c, acc3, wr3);                        // E3's bias and first weights fly while the image is copied
   // fragment (step, fb, piece, lane) -> image row 32*fb + (lane & 31), columns 16*step + 8*(lane >> 5) .. +7 of plane `piece`
   const h8* src = xin + (size_t)tile * buf_steps * STEP_UNITS;
   for (int i = tid; i < 16 * 128; i += 256) {                 // E2's output: 256 columns = 16 K steps, this face block
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(hx::Args a, const h8* __re
         src[(size_t)step * STEP_UNITS + (fbsel * 2 + piece) * 64 + l];
   }
   __syncthreads();
-  hx::tail_stages<true>(c, a, row0, fbsel);
+  hx::tail_stages<true>(c, a, row0, acc3, wr3, fbsel);
 }
 
 static int e0_k16(int F) { return (F + 2 * hx::XS_COLS - 1) / (2 * hx::XS_COLS) * (2 * hx::XS_STEPS); }   // as pack.cpp

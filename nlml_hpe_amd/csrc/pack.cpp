@@ -221,6 +221,21 @@ int pack_blob(int F, int mode, const float* const enc_w[6], const float* const e
     cur = b_off + (size_t)d.jobs * d.nb * 8;
   }
   hdr->total16 = (uint32_t)(need / 16);
+  if (f16x2) {   // the split-f16 kernels compute these offsets from k16_e0 instead of reading them (encoder_heads_f16x2_dev.h)
+    for (int s = 0; s < NUM_STAGES; ++s) {
+      const uint32_t k = hdr->k8_e0;
+      const uint32_t jw = (s == ST_E0) ? (uint32_t)hx::kStages[s].nb * 64 * hx::PIECES * k
+                                       : (uint32_t)hx::kStages[s].k8 * hx::kStages[s].nb * 64 * hx::PIECES;
+      uint32_t w = sizeof(Header) / 16;
+      for (int t = 0; t < s; ++t) {
+        const uint32_t jt = (t == ST_E0) ? (uint32_t)hx::kStages[t].nb * 64 * hx::PIECES * k
+                                         : (uint32_t)hx::kStages[t].k8 * hx::kStages[t].nb * 64 * hx::PIECES;
+        w += hx::kStages[t].jobs * (jt + hx::kStages[t].nb * 8);
+      }
+      if (hdr->w_off[s] != w || hdr->job_w16[s] != jw || hdr->b_off[s] != w + hx::kStages[s].jobs * jw)
+        return fail(NLML_E_BADARG, "pack: blob layout differs from the split-f16 kernels' offset formula");
+    }
+  }
   return 0;
 }
 
