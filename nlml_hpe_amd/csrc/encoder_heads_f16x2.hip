@@ -180,6 +180,9 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
                                                : *reinterpret_cast<const h8*>(xnext + pp * P_XS + fb * FB);
               },
               [&](int m) {   // slab s+2's staging in the step's free (odd) slots: step 0 normalises, step 1 splits, stores, reloads
+#ifdef HX_ABL_NOSTAGE
+                return;      // timing-only ablation (wrong results)
+#endif
                 if ((m & 1) == 0) return;
                 const int j = m >> 1;                        // free slot 0..11 of this step
                 if (kk == 0) {
@@ -195,7 +198,9 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
                 }
               });
     }
+#ifndef HX_ABL_NOBAR
     __syncthreads();
+#endif
     const int t0 = o0;   // rotate: (o0, o1, o2) <- (o1, o2, o0)
     o0 = o1; o1 = o2; o2 = t0;
   };

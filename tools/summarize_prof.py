@@ -18,7 +18,7 @@ from collections import defaultdict
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 path_key = sys.argv[2] if len(sys.argv) > 2 else "f16x2_fused"      # <mode>_<path> of the profiled bench.py run
-traffic_tag = sys.argv[3] if len(sys.argv) > 3 else "r01"           # bench.py reads profiles/r01_pmc_traffic.json
+traffic_tag = sys.argv[3] if len(sys.argv) > 3 else tag             # bench.py reads profiles/<latest round>_pmc_traffic.json
 bench_args = sys.argv[4] if len(sys.argv) > 4 else ""
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
@@ -84,6 +84,8 @@ if dom and "hbm_bytes_per_launch_corrected" in summary[dom]:
     cur = json.load(open(tp)) if os.path.exists(tp) else {}
     cur[f"{path_key}_bytes_per_launch"] = summary[dom]["hbm_bytes_per_launch_corrected"]
     cur[f"{path_key}_kernel"] = dom
+    if "avg_duration_ns_trace" in summary[dom]:
+        cur[f"{path_key}_kernel_ms"] = summary[dom]["avg_duration_ns_trace"] / 1e6
     cur["correction"] = "(2*FETCH_SIZE + WRITE_SIZE) * 1024, MI355X_MICROARCH.md HBM section"
     json.dump(cur, open(tp, "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_pmc_summary.md")).read())
