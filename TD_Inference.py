@@ -21,6 +21,9 @@ def inference(argv=None):
     ap = argparse.ArgumentParser(description="Inference the head pose of input faces by the TD path")
     ap.add_argument("--image_path", type=str, required=True, help="landmarks .npy/.npz (f32[N,468,3])")
     ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--order", choices=["reference", "fast"], default="reference",
+                    help="objective's operation order: reference = the reference's bits and scipy's own end point (default); "
+                         "fast = f64 matrix cores, end point within 2e-2 deg")
     args = ap.parse_args(argv)
     torch.cuda.set_device(torch.device(args.device))
 
@@ -30,7 +33,7 @@ def inference(argv=None):
     u_id_shape = art["U_id"][1].size                                            # :51
     t0 = time.time()
     deg = TD_Tester.Test_batch(art["W"], x, u_id_shape, art["optimized_yaw"][0:3, :], art["optimized_pitch"][0:3, :],
-                               art["optimized_roll"][0:3, :])                   # :56
+                               art["optimized_roll"][0:3, :], order=args.order)  # :56
     dt = time.time() - t0
     for i, (y, p, r) in enumerate(deg):
         tag = f"[{i}] " if len(deg) > 1 else ""

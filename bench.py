@@ -451,7 +451,25 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     ex["td_powell_end_to_end"] = {"faces": int(Xg.shape[0]), "seconds": dt, "faces_per_sec": Xg.shape[0] / dt,
                                   "mean_nfev": float(nf.mean()), "max_nfev": float(nf.max()),
                                   "face_evals_per_sec": float(nf.sum()) / dt,
-                                  "converged_frac": float((res["status"] == 1).double().mean())}
+                                  "converged_frac": float((res["status"] == 1).double().mean()),
+                                  "order": "fast (f64 matrix cores; end point within 2e-2 deg of scipy's)"}
+    # the same 4,096 faces in the REFERENCE's operation order (np.einsum's loop + numpy's pairwise sum on the vector ALUs):
+    # the reference's objective bits, scipy's own trajectory and end point (FX4 / FX5 bit-exact)
+    ops.tucker_powell(Wm, Xg[:64], cp, order="reference")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res_r = ops.tucker_powell(Wm, Xg, cp, order="reference")
+    torch.cuda.synchronize()
+    dt_r = time.perf_counter() - t0
+    nfr = res_r["nfev"].double()
+    dd = torch.rad2deg((res_r["x"][:, :3] - res["x"][:, :3]).abs())
+    ex["td_powell_reference_order"] = {"faces": int(Xg.shape[0]), "seconds": dt_r, "faces_per_sec": Xg.shape[0] / dt_r,
+                                       "mean_nfev": float(nfr.mean()), "face_evals_per_sec": float(nfr.sum()) / dt_r,
+                                       "fast_vs_reference_order_max_deg": float(dd.max()),
+                                       "fast_vs_reference_order_median_deg": float(dd.median())}
+    ms = time_kernel(lambda: ops.tucker_objective(Wm, feats[:N], P, cp, order="reference"), 5, warm=1)
+    ex["k3_tucker_objective_reference_order"] = {"evals_per_sec": N / ms * 1e3, "n": N,
+                                                 "note": "5 separately rounded f64 operations per (q, m) on the vector ALUs"}
     return ex
 
 

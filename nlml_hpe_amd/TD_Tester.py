@@ -59,19 +59,28 @@ def func(w, params):
     return a * np.cos(b * w + c) + d
 
 
-def objective_batch(params, W, X, params_y, params_p, params_r, x_index=None, return_xhat=False):
+# Operation order of the device objective.  "reference" = np.einsum's own loop order and numpy's pairwise sum: the reference's
+# objective bit for bit, hence scipy's own Powell trajectory and final angles (FX4, FX5) -- the default of the reference-named
+# functions objective() and Test().  "fast" = the GEMM form on the f64 matrix cores (<= 1e-12 relative; Powell's end point within
+# 2e-2 deg) -- the default of the batched forms this build adds.
+ORDER_REFERENCE, ORDER_FAST = "reference", "fast"
+
+
+def objective_batch(params, W, X, params_y, params_p, params_r, x_index=None, return_xhat=False, order=ORDER_FAST):
     """params f64[N,8]; X f32[M,1404] (M == N, or rows selected by x_index i32[N]) -> err f64[N] (numpy)."""
     P = torch.from_numpy(np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 8)).to(_dev())
     xi = None if x_index is None else torch.from_numpy(np.ascontiguousarray(x_index, dtype=np.int32)).to(_dev())
-    out = ops.tucker_objective(_wm(W), _x(X), P, _cos(params_y, params_p, params_r), x_index=xi, return_xhat=return_xhat)
+    out = ops.tucker_objective(_wm(W), _x(X), P, _cos(params_y, params_p, params_r), x_index=xi, return_xhat=return_xhat,
+                               order=order)
     if return_xhat:
         return out[0].cpu().numpy(), out[1].cpu().numpy()
     return out.cpu().numpy()
 
 
-def objective(params, W, x, params_y, params_p, params_r):
-    """One evaluation, same signature as the reference (:31); x may be a torch tensor or an array."""
-    return float(objective_batch(np.asarray(params, dtype=np.float64)[None], W, x, params_y, params_p, params_r)[0])
+def objective(params, W, x, params_y, params_p, params_r, order=ORDER_REFERENCE):
+    """One evaluation, same signature as the reference (:31); x may be a torch tensor or an array.  In the default order the
+    value is the reference's, bit for bit."""
+    return float(objective_batch(np.asarray(params, dtype=np.float64)[None], W, x, params_y, params_p, params_r, order=order)[0])
 
 
 def compute_gradient_batch(params, W, X, params_y, params_p, params_r):
@@ -117,18 +126,21 @@ def compute_gradient(params, W, x, params_y, params_p, params_r):
     return compute_gradient_batch(np.asarray(params, dtype=np.float64)[None], W, x, params_y, params_p, params_r)[0]
 
 
-def Test_batch(W, X, u_id_shape, optimized_params_y, optimized_params_p, optimized_params_r, return_info=False):
+def Test_batch(W, X, u_id_shape, optimized_params_y, optimized_params_p, optimized_params_r, return_info=False,
+               order=ORDER_FAST):
     """Rows of X f32[N,1404] -> degrees f64[N,3] by device-side lock-step Powell (one launch)."""
     if u_id_shape != 5:
         raise ValueError("the device minimiser is built for u_id of size 5 (outputs/features/Factor_Matrices.npz)")
-    res = ops.tucker_powell(_wm(W), _x(X), _cos(optimized_params_y, optimized_params_p, optimized_params_r))
+    res = ops.tucker_powell(_wm(W), _x(X), _cos(optimized_params_y, optimized_params_p, optimized_params_r), order=order)
     deg = np.degrees(res["x"].cpu().numpy())[:, :3]                               # :196-199
     if return_info:
         return deg, {k: v.cpu().numpy() for k, v in res.items()}
     return deg
 
 
-def Test(W, x, u_id_shape, optimized_params_y, optimized_params_p, optimized_params_r, u_id, f_y, f_p, f_r):
-    """Same signature and return tuple as the reference (:162-163, :291): u_id is passed through."""
-    deg = Test_batch(W, x, u_id_shape, optimized_params_y, optimized_params_p, optimized_params_r)[0]
+def Test(W, x, u_id_shape, optimized_params_y, optimized_params_p, optimized_params_r, u_id, f_y, f_p, f_r,
+         order=ORDER_REFERENCE):
+    """Same signature and return tuple as the reference (:162-163, :291): u_id is passed through.  Default order: the reference's
+    (scipy's own trajectory and end point on its own objective bits; ~25 ms per face instead of the reference's 2-4 s)."""
+    deg = Test_batch(W, x, u_id_shape, optimized_params_y, optimized_params_p, optimized_params_r, order=order)[0]
     return deg[0], deg[1], deg[2], u_id

@@ -37,6 +37,10 @@ SYMBOLS = {
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlml_tucker_powell": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nlml_tucker_objective_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "nlml_tucker_powell_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "nlml_video_post": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double,
                                   C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nlml_cosine_table": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -51,6 +55,19 @@ MODE_F32 = 0
 MODE_BF16 = 1
 MODE_F16X2 = 2
 MODE_NAMES = {"f32": MODE_F32, "bf16": MODE_BF16, "f16x2": MODE_F16X2}
+TD_ORDER_FAST = 0          # GEMM on the f64 matrix cores (<= 1e-12 rel. of the reference's objective)
+TD_ORDER_REFERENCE = 1     # np.einsum's own operation order + numpy's pairwise sum: the reference's bits
+TD_ORDER_NAMES = {"fast": TD_ORDER_FAST, "reference": TD_ORDER_REFERENCE}
+
+
+def td_order_from_name(order) -> int:
+    if isinstance(order, str):
+        if order not in TD_ORDER_NAMES:
+            raise ValueError(f"unknown TD order {order!r}; expected one of {sorted(TD_ORDER_NAMES)}")
+        return TD_ORDER_NAMES[order]
+    if int(order) not in TD_ORDER_NAMES.values():
+        raise ValueError(f"unknown TD order {order!r}")
+    return int(order)
 
 
 def mode_from_name(mode) -> int:

@@ -120,7 +120,17 @@ int nlml_tucker_objective(const float* Wm, const float* x, int64_t ldx, const in
   if (N < 0) return fail(NLML_E_BADARG, "tucker_objective: negative N");
   if (N > 0 && (!Wm || !x || !params || !cos_params || !err)) return fail(NLML_E_BADARG, "tucker_objective: null buffer");
   if (N > 0 && ldx < NLML_F_REFERENCE) return fail(NLML_E_BADARG, "tucker_objective: ldx < 1404");
-  return launch_tucker_objective(Wm, x, ldx, x_index, params, cos_params, N, err, x_hat, stream);
+  return launch_tucker_objective(Wm, x, ldx, x_index, params, cos_params, N, err, x_hat, NLML_TD_ORDER_FAST, stream);
+}
+
+int nlml_tucker_objective_ex(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,
+                             const double* params, const double* cos_params, int64_t N, double* err, double* x_hat,
+                             int order, void* stream) {
+  if (order != NLML_TD_ORDER_FAST && order != NLML_TD_ORDER_REFERENCE) return fail(NLML_E_BADARG, "tucker_objective: unknown order");
+  if (N < 0) return fail(NLML_E_BADARG, "tucker_objective: negative N");
+  if (N > 0 && (!Wm || !x || !params || !cos_params || !err)) return fail(NLML_E_BADARG, "tucker_objective: null buffer");
+  if (N > 0 && ldx < NLML_F_REFERENCE) return fail(NLML_E_BADARG, "tucker_objective: ldx < 1404");
+  return launch_tucker_objective(Wm, x, ldx, x_index, params, cos_params, N, err, x_hat, order, stream);
 }
 
 int nlml_video_post(const float* pose_rad, const float* raw, const uint8_t* valid, int64_t S, double frame_w,
@@ -179,7 +189,17 @@ int nlml_tucker_powell(const float* Wm, const float* x, int64_t ldx, const doubl
   if (N < 0) return fail(NLML_E_BADARG, "tucker_powell: negative N");
   if (N > 0 && (!Wm || !x || !cos_params || !result)) return fail(NLML_E_BADARG, "tucker_powell: null buffer");
   if (N > 0 && ldx < NLML_F_REFERENCE) return fail(NLML_E_BADARG, "tucker_powell: ldx < 1404");
-  return launch_tucker_powell(Wm, x, ldx, cos_params, N, x0, result, fval, nfev, nit, status, stream);
+  return launch_tucker_powell(Wm, x, ldx, cos_params, N, x0, result, fval, nfev, nit, status, NLML_TD_ORDER_FAST, stream);
+}
+
+int nlml_tucker_powell_ex(const float* Wm, const float* x, int64_t ldx, const double* cos_params, int64_t N,
+                          const double* x0, double* result, double* fval, int32_t* nfev, int32_t* nit,
+                          int32_t* status, int order, void* stream) {
+  if (order != NLML_TD_ORDER_FAST && order != NLML_TD_ORDER_REFERENCE) return fail(NLML_E_BADARG, "tucker_powell: unknown order");
+  if (N < 0) return fail(NLML_E_BADARG, "tucker_powell: negative N");
+  if (N > 0 && (!Wm || !x || !cos_params || !result)) return fail(NLML_E_BADARG, "tucker_powell: null buffer");
+  if (N > 0 && ldx < NLML_F_REFERENCE) return fail(NLML_E_BADARG, "tucker_powell: ldx < 1404");
+  return launch_tucker_powell(Wm, x, ldx, cos_params, N, x0, result, fval, nfev, nit, status, order, stream);
 }
 
 }  // extern "C"

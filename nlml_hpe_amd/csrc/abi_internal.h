@@ -40,12 +40,12 @@ int launch_normalize_ipd(const float* raw, int64_t B, int normalize, float* out,
 // tucker_objective.hip
 int launch_tucker_objective(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,
                             const double* params, const double* cos_params, int64_t N,
-                            double* err, double* x_hat, void* stream);
+                            double* err, double* x_hat, int order, void* stream);
 
 // tucker_powell.hip
 int launch_tucker_powell(const float* Wm, const float* x, int64_t ldx, const double* cos_params, int64_t N,
                          const double* x0, double* result, double* fval, int32_t* nfev, int32_t* nit,
-                         int32_t* status, void* stream);
+                         int32_t* status, int order, void* stream);
 
 // video_post.hip
 int launch_video_post(const float* pose_rad, const float* raw, const uint8_t* valid, int64_t S, double frame_w,

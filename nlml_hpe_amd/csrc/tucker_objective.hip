@@ -8,6 +8,7 @@
 
 #include "abi_internal.h"
 #include "tucker_common.h"
+#include "tucker_ref.h"
 
 namespace nlml {
 
@@ -57,11 +58,39 @@ __global__ __launch_bounds__(TNT, 2) void tucker_objective_kernel(
   if (tid < EV && e0 + tid < N) err[e0 + tid] = tucker_err(sh, tid);
 }
 
+// NLML_TD_ORDER_REFERENCE: the same 16 evaluations per workgroup in the reference's operation order (tucker_ref.h)
+__global__ __launch_bounds__(TNT, 1) void tucker_objective_ref_kernel(
+    const float* __restrict__ Wm, const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ x_index,
+    const double* __restrict__ params, const double* __restrict__ cosp, int64_t N, double* __restrict__ err,
+    double* __restrict__ x_hat) {
+  __shared__ __attribute__((aligned(16))) TuckerShared sh;
+  __shared__ __attribute__((aligned(16))) TuckerRefShared rs;
+  const int tid = threadIdx.x;
+  const int64_t e0 = (int64_t)blockIdx.x * EV;
+  double cp4[4] = {0, 0, 0, 0};
+  if (tid < EV * 9) {
+    const double* c4 = cosp + ((tid % 9) / 3 * 3 + tid % 3) * 4;
+    cp4[0] = c4[0]; cp4[1] = c4[1]; cp4[2] = c4[2]; cp4[3] = c4[3];
+  }
+  GlobalPar par{params + e0 * 8, N - e0};
+  tucker_fvec(sh, par, cp4, tid);
+  const int64_t left = N - e0;
+  const int mask = left >= EV ? 0xffff : ((1 << (int)left) - 1);
+  tucker_ref_eval(sh, rs, Wm, par, mask,
+                  [&](int slot) { const int64_t n = e0 + slot; return x + (x_index ? (int64_t)x_index[n] : n) * ldx; },
+                  [&](int slot) { return x_hat ? x_hat + (e0 + slot) * TM : (double*)nullptr; }, tid);
+  if (tid < EV && e0 + tid < N) err[e0 + tid] = rs.err[tid];
+}
+
 int launch_tucker_objective(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,
                             const double* params, const double* cos_params, int64_t N, double* err,
-                            double* x_hat, void* stream) {
+                            double* x_hat, int order, void* stream) {
   if (N == 0) return 0;
   const dim3 grid((unsigned)((N + EV - 1) / EV)), block(TNT);
+  if (order == NLML_TD_ORDER_REFERENCE)
+    hipLaunchKernelGGL(tucker_objective_ref_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), Wm, x, ldx,
+                       x_index, params, cos_params, N, err, x_hat);
+  else
   hipLaunchKernelGGL(tucker_objective_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), Wm, x, ldx,
                      x_index, params, cos_params, N, err, x_hat);
   const hipError_t e = hipGetLastError();

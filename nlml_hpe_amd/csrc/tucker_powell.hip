@@ -18,6 +18,7 @@
 #include "abi_internal.h"
 #include "powell.h"
 #include "tucker_common.h"
+#include "tucker_ref.h"
 
 namespace nlml {
 
@@ -34,7 +35,11 @@ struct LdsPar {
   __device__ __forceinline__ double operator()(int e, int k) const { return p[e][k]; }
 };
 
-__global__ __launch_bounds__(TNT, 2) void tucker_powell_kernel(
+// ORDER = NLML_TD_ORDER_FAST: the objective as a GEMM on the f64 matrix cores (tucker_common.h); NLML_TD_ORDER_REFERENCE: in the
+// reference's own operation order (tucker_ref.h) -- then the machines receive the reference's objective values bit for bit and
+// walk scipy's trajectory (FX5: same evaluation counts, same final angles).
+template <int ORDER>
+__global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void tucker_powell_kernel(
     const float* __restrict__ Wm, const float* __restrict__ x, int64_t ldx, const double* __restrict__ cosp,
     int64_t N, const double* __restrict__ x0, double* __restrict__ result, double* __restrict__ fval,
     int32_t* __restrict__ nfev, int32_t* __restrict__ nit, int32_t* __restrict__ status) {
@@ -85,6 +90,24 @@ __global__ __launch_bounds__(TNT, 2) void tucker_powell_kernel(
 #pragma unroll
     for (int e = 0; e < EV; ++e) live_mask |= need[e] << e;
     if (!live_mask) break;
+
+    if constexpr (ORDER == NLML_TD_ORDER_REFERENCE) {
+      __shared__ __attribute__((aligned(16))) TuckerRefShared rs;
+      tucker_fvec(sh, lp, cp4, tid);
+      tucker_ref_eval(sh, rs, Wm, lp, live_mask,
+                      [&](int slot) { int64_t n = e0 + slot; n = n < N ? n : N - 1; return x + n * ldx; },
+                      [&](int) { return (double*)nullptr; }, tid);
+      if (me >= 0 && need[me]) {
+        const bool nd = powell_step_call(&st[me], rs.err[me]);
+        need[me] = nd ? 1 : 0;
+        if (nd) {
+#pragma unroll
+          for (int k = 0; k < PW_N; ++k) par[me][k] = st[me].xeval[k];
+        }
+      }
+      __syncthreads();
+      continue;
+    }
 
     tucker_coef(sh, lp, cp4, tid);
     if (__popc(live_mask) <= PW_FEW) {
@@ -153,10 +176,14 @@ __global__ __launch_bounds__(TNT, 2) void tucker_powell_kernel(
 
 int launch_tucker_powell(const float* Wm, const float* x, int64_t ldx, const double* cos_params, int64_t N,
                          const double* x0, double* result, double* fval, int32_t* nfev, int32_t* nit,
-                         int32_t* status, void* stream) {
+                         int32_t* status, int order, void* stream) {
   if (N == 0) return 0;
   const dim3 grid((unsigned)((N + EV - 1) / EV)), block(TNT);
-  hipLaunchKernelGGL(tucker_powell_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), Wm, x, ldx,
+  if (order == NLML_TD_ORDER_REFERENCE)
+    hipLaunchKernelGGL((tucker_powell_kernel<NLML_TD_ORDER_REFERENCE>), grid, block, 0, reinterpret_cast<hipStream_t>(stream),
+                       Wm, x, ldx, cos_params, N, x0, result, fval, nfev, nit, status);
+  else
+  hipLaunchKernelGGL((tucker_powell_kernel<NLML_TD_ORDER_FAST>), grid, block, 0, reinterpret_cast<hipStream_t>(stream), Wm, x, ldx,
                      cos_params, N, x0, result, fval, nfev, nit, status);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));

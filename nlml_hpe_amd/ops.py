@@ -138,9 +138,11 @@ def landmarks_to_pose(raw: torch.Tensor, blob: torch.Tensor, normalize: bool = T
 
 
 def tucker_objective(Wm: torch.Tensor, x: torch.Tensor, params: torch.Tensor, cos_params: torch.Tensor,
-                     x_index: torch.Tensor | None = None, return_xhat: bool = False):
+                     x_index: torch.Tensor | None = None, return_xhat: bool = False, order="fast"):
     """Batched objective (TD_Tester.py:31-58): Wm f32[135,1404], x f32[M,1404], params f64[N,8],
-    cos_params f64[3,3,4] -> err f64[N] (+ x_hat f64[N,1404])."""
+    cos_params f64[3,3,4] -> err f64[N] (+ x_hat f64[N,1404]).  order: "fast" (f64 matrix cores, <= 1e-12 relative) or
+    "reference" (np.einsum's operation order and numpy's pairwise sum: the reference's bits)."""
+    order = _lib.td_order_from_name(order)
     _need_cuda(Wm, "Wm", torch.float32)
     _need_cuda(x, "x", torch.float32)
     _need_cuda(params, "params", torch.float64)
@@ -167,10 +169,10 @@ def tucker_objective(Wm: torch.Tensor, x: torch.Tensor, params: torch.Tensor, co
     err = torch.empty((N,), dtype=torch.float64, device=x.device)
     xh = torch.empty((N, F_REF), dtype=torch.float64, device=x.device) if return_xhat else None
     with _on_device_of(("x", x), ("Wm", Wm), ("params", params), ("cos_params", cos_params), ("x_index", x_index)) as stream:
-        _lib.check(_lib.lib().nlml_tucker_objective(
+        _lib.check(_lib.lib().nlml_tucker_objective_ex(
             Wm.data_ptr(), x.data_ptr(), F_REF, x_index.data_ptr() if x_index is not None else None,
             params.data_ptr(), cos_params.data_ptr(), N, err.data_ptr(),
-            xh.data_ptr() if xh is not None else None, stream), "nlml_tucker_objective")
+            xh.data_ptr() if xh is not None else None, order, stream), "nlml_tucker_objective_ex")
     return (err, xh) if return_xhat else err
 
 
@@ -221,8 +223,9 @@ except Exception as _e:  # pragma: no cover - registration is a convenience; the
     warnings.warn(f"torch.ops.nlml_hpe registration skipped: {_e}")
 
 
-def tucker_powell(Wm: torch.Tensor, x: torch.Tensor, cos_params: torch.Tensor, x0: torch.Tensor | None = None):
-    """Batched Test() (TD_Tester.py:162-199): one Powell minimisation per row of x, on device.
+def tucker_powell(Wm: torch.Tensor, x: torch.Tensor, cos_params: torch.Tensor, x0: torch.Tensor | None = None, order="fast"):
+    """Batched Test() (TD_Tester.py:162-199): one Powell minimisation per row of x, on device.  order as in tucker_objective:
+    "reference" walks scipy's own trajectory on the reference's objective bits (slower); "fast" ends within 2e-2 deg of it.
 
     Returns dict(x=f64[N,8] (w_y,w_p,w_r radians + u_id), fun=f64[N], nfev=i32[N], nit=i32[N], status=i32[N]).
     """
@@ -242,6 +245,7 @@ def tucker_powell(Wm: torch.Tensor, x: torch.Tensor, cos_params: torch.Tensor, x
         if tuple(x0.shape) != (N, 8):
             raise ValueError(f"x0: expected [{N},8], got {tuple(x0.shape)}")
         x0 = x0.contiguous()
+    order = _lib.td_order_from_name(order)
     dev = x.device
     res = torch.empty((N, 8), dtype=torch.float64, device=dev)
     fun = torch.empty((N,), dtype=torch.float64, device=dev)
@@ -249,10 +253,10 @@ def tucker_powell(Wm: torch.Tensor, x: torch.Tensor, cos_params: torch.Tensor, x
     nit = torch.empty((N,), dtype=torch.int32, device=dev)
     status = torch.empty((N,), dtype=torch.int32, device=dev)
     with _on_device_of(("x", x), ("Wm", Wm), ("cos_params", cos_params), ("x0", x0)) as stream:
-        _lib.check(_lib.lib().nlml_tucker_powell(Wm.data_ptr(), x.data_ptr(), F_REF, cos_params.data_ptr(), N,
-                                                 x0.data_ptr() if x0 is not None else None, res.data_ptr(), fun.data_ptr(),
-                                                 nfev.data_ptr(), nit.data_ptr(), status.data_ptr(), stream),
-                   "nlml_tucker_powell")
+        _lib.check(_lib.lib().nlml_tucker_powell_ex(Wm.data_ptr(), x.data_ptr(), F_REF, cos_params.data_ptr(), N,
+                                                    x0.data_ptr() if x0 is not None else None, res.data_ptr(), fun.data_ptr(),
+                                                    nfev.data_ptr(), nit.data_ptr(), status.data_ptr(), order, stream),
+                   "nlml_tucker_powell_ex")
     return {"x": res, "fun": fun, "nfev": nfev, "nit": nit, "status": status}
 
 

@@ -59,7 +59,9 @@ def encoder_heads(x: np.ndarray, params, order: int = 1, want_latent=False, want
     return res[0] if len(res) == 1 else tuple(res)
 
 
-def tucker_objective(Wm, x, params, cosp, want_xhat=False, device_order=False):
+def tucker_objective(Wm, x, params, cosp, want_xhat=False, device_order=False, reference_order=False):
+    """reference_order: np.einsum's own (i,j,k,l)-outer sum of separately rounded products and numpy's pairwise np.sum --
+    bit-identical to the reference's objective (FX4); device_order: the fast kernel's reduction tree."""
     Wm = np.ascontiguousarray(Wm, dtype=np.float32).reshape(135, 1404)
     x = np.ascontiguousarray(x, dtype=np.float32)
     params = np.ascontiguousarray(params, dtype=np.float64)
@@ -67,6 +69,10 @@ def tucker_objective(Wm, x, params, cosp, want_xhat=False, device_order=False):
     N = params.shape[0]
     err = np.empty(N)
     xh = np.empty((N, 1404)) if want_xhat else None
+    if reference_order:
+        lib().oracle_tucker_objective_reforder(_p(Wm), _p(x), _p(params), _p(cosp), C.c_int64(N), _p(err),
+                                               _p(xh) if want_xhat else None)
+        return (err, xh) if want_xhat else err
     lib().oracle_tucker_objective(_p(Wm), _p(x), _p(params), _p(cosp), C.c_int64(N), _p(err), _p(xh) if want_xhat else None,
                                   C.c_int(int(device_order)))
     return (err, xh) if want_xhat else err

@@ -128,6 +128,68 @@ static double residual_device_order(const float* xrow, const double* acc) {
   return 0.5 * (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
 }
 
+/* numpy's pairwise summation (numpy/_core/src/umath/loops_utils.h.src, DOUBLE_pairwise_sum; what np.sum at TD_Tester.py:49 runs on
+ * a contiguous f64 vector): blocks of at most 128 elements are summed in eight strided partial sums, combined as
+ * ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), the remainder added one by one; longer ranges split at n/2 rounded down to a multiple of 8. */
+static double np_pairwise_sum(const double* a, int n) {
+  if (n < 8) {
+    double res = 0.0;
+    for (int i = 0; i < n; ++i) res += a[i];
+    return res;
+  }
+  if (n <= 128) {
+    double r[8];
+    int i;
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+/* The objective in the REFERENCE's own operation order (TD_Tester.py:46,49): np.einsum('ijklm,i,j,k,l->m') with five operands
+ * runs numpy's generic sum-of-products loop -- for every (i,j,k,l), in that nesting order, and every m:
+ *     x_hat[m] = ((((W[i,j,k,l,m] * u_i) * f_yj) * f_pk) * f_rl) + x_hat[m]
+ * every operation rounded to f64 on its own (no fused multiply-add) -- then 0.5 * np.sum((x - x_hat)**2) with the pairwise sum
+ * above.  Bit-identical to FX4's err and x_hat (tests/test_oracle_golden.py). */
+void oracle_tucker_objective_reforder(const float* Wm, const float* x, const double* params, const double* cosp,
+                                      int64_t N, double* err, double* xhat) {
+#pragma omp parallel for schedule(static)
+  for (int64_t n = 0; n < N; ++n) {
+    const double* p = params + n * 8;
+    double f[3][3];
+    for (int a = 0; a < 3; ++a)
+      for (int j = 0; j < 3; ++j) {
+        const double* cp = cosp + (a * 3 + j) * 4;
+        f[a][j] = (double)(float)(cp[0] * cos(cp[1] * p[a] + cp[2]) + cp[3]);
+      }
+    double acc[1404], d2[1404];
+    for (int m = 0; m < 1404; ++m) acc[m] = 0.0;
+    for (int q = 0; q < 135; ++q) {
+      const double u = p[3 + q / 27], fy = f[0][(q / 9) % 3], fp = f[1][(q / 3) % 3], fr = f[2][q % 3];
+      const float* w = Wm + (size_t)q * 1404;
+      for (int m = 0; m < 1404; ++m) {
+        double t = (double)w[m] * u;
+        t = t * fy;
+        t = t * fp;
+        t = t * fr;
+        acc[m] = t + acc[m];
+      }
+    }
+    for (int m = 0; m < 1404; ++m) {
+      const double d = (double)x[n * 1404 + m] - acc[m];
+      d2[m] = d * d;
+      if (xhat) xhat[n * 1404 + m] = acc[m];
+    }
+    err[n] = 0.5 * np_pairwise_sum(d2, 1404);
+  }
+}
+
 void oracle_tucker_objective(const float* Wm, const float* x, const double* params, const double* cosp,
                              int64_t N, double* err, double* xhat, int device_order) {
 #pragma omp parallel for schedule(static)

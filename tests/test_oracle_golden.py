@@ -111,6 +111,10 @@ def test_fx4_td_objective(golden_dir, tucker_art):
     ec, xhc = CO.tucker_objective(W, g["x"], g["params"], np.stack([Py, Pp, Pr]), want_xhat=True)   # plain C
     assert np.max(np.abs(ec - g["err"]) / g["err"]) <= 1e-12
     assert np.max(np.abs(xhc[:8] - g["x_hat"])) <= 1e-12 * np.abs(g["x_hat"]).max()
+    # plain C in the REFERENCE's operation order (np.einsum's sum-of-products loop, numpy's pairwise np.sum): the same bits
+    er, xhr = CO.tucker_objective(W, g["x"], g["params"], np.stack([Py, Pp, Pr]), want_xhat=True, reference_order=True)
+    assert np.array_equal(er, g["err"])
+    assert np.array_equal(xhr[:8], g["x_hat"])
 
 
 def test_fx5_td_end_to_end_one_face(golden_dir, tucker_art):
