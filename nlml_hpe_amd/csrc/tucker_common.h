@@ -8,19 +8,22 @@
 //                 v_mfma_f64_16x16x4_f64, q ascending (one fma chain per output)                 (:46)
 //   err[e]      = 0.5 * sum_m (x[m]-x_hat[m])^2   fixed-order reduction                          (:49)
 //
-// Workgroup = 512 threads = 8 waves; the 1404 columns are 88 blocks of 16 and wave w owns blocks
-// 11w .. 11w+10 (44 f64 accumulators per lane).  Per K step of 4 a wave reads its A fragment (16
-// evaluations x 4 coefficients) from LDS once and, for each of its 11 blocks, one dword per lane of Wm
-// (4 rows x 64 B, f32 -> f64 in the register) -- each row of Wm is read once per workgroup, i.e.
-// once per 16 evaluations.  One MFMA (64 cycles) replaces 16 v_fma_f64 wave-instructions, so the
-// loads, conversions and LDS reads hide in its shadow instead of competing for issue slots
-// (the VALU form of this kernel reached 29 % of the f64 peak).
+// Workgroup = 512 threads = 8 waves; wave w owns the 176 columns from tcol0(w) = 176 w (the last wave: 1228, so that it ends
+// at column 1403; its first four columns repeat wave 6's last four and are ignored) as 11 MFMA column blocks: block mb's MFMA
+// column j is column  tcol0(w) + 11 j + mb  (44 f64 accumulators per lane).  A lane therefore needs ELEVEN CONSECUTIVE floats
+// of a Wm row per K step -- three loads of 16 + 16 + 12 bytes (704 contiguous bytes per row and wave) -- instead of the eleven
+// single-dword loads of the blocks-of-16-consecutive-columns map this kernel started with: those were 256-byte wave
+// instructions, and the CU's address path (one wave-instruction per ~16 cycles), not the matrix pipe, set the pace (a
+// timing-only build with 3 of the 11 loads ran at 66 % of the f64 peak instead of 56 %).  Per K step of 4 a wave reads its A
+// fragment (16 evaluations x 4 coefficients) from LDS once; each row of Wm is read once per workgroup, i.e. once per 16
+// evaluations; f32 -> f64 in the register.  One MFMA (64 cycles) replaces 16 v_fma_f64 wave-instructions (the VALU form of this
+// kernel reached 29 % of the f64 peak).
 //
 // MFMA operand / result maps (f64 16x16x4, cdna_hip_programming.md section 3): lane l supplies
 // A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; result register r of lane l is D[(l>>4) + 4r][l&15].
 //
 // Reduction order (the C oracle's device_order mode replays it bit for bit):
-//   lane:  for each of its 4 evaluations, fma chain over its 11 columns in ascending block order;
+//   lane:  for each of its 4 evaluations, fma chain over its 11 (consecutive) columns in ascending order, dead columns skipped;
 //   wave:  xor butterfly over the 16 lanes of a column group, offsets 1, 2, 4, 8;
 //   block: ((w0+w1)+(w2+w3)) + ((w4+w5)+(w6+w7)); then * 0.5.
 #pragma once
@@ -38,8 +41,28 @@ constexpr int EV = 16;                  // evaluations per workgroup = MFMA rows
 constexpr int TNT = 512;                // threads per workgroup
 constexpr int TNW = TNT / 64;           // 8 waves
 constexpr int TQS = (TQ + 3) / 4;       // 34 K steps of 4 (K padded to 136)
-constexpr int MBW = 11;                 // 16-column blocks per wave: 8 * 11 * 16 = 1408 >= 1404
-constexpr int TRING = 3;                // Wm prefetch ring (K steps)
+constexpr int MBW = 11;                 // MFMA column blocks per wave = consecutive columns per lane: 8 * 16 * 11 = 1408 >= 1404
+constexpr int TWC = 16 * MBW;           // 176 columns per wave
+#ifndef K3_TRING
+#define K3_TRING 3
+#endif
+constexpr int TRING = K3_TRING;         // Wm prefetch ring (K steps)
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x3_t __attribute__((ext_vector_type(3)));
+
+// first column of wave w, and whether (lane column j, block mb) of wave w is a column of its own (wave 7 starts 4 early)
+__host__ __device__ __forceinline__ constexpr int tcol0(int w) { return w < TNW - 1 ? TWC * w : TM - TWC; }
+__host__ __device__ __forceinline__ constexpr bool tcol_live(int w, int j, int mb) { return w < TNW - 1 || MBW * j + mb >= TNW * TWC - TM; }
+
+// eleven consecutive floats from p (4-byte aligned): three loads
+__device__ __forceinline__ void load11(const float* __restrict__ p, float (&v)[MBW]) {
+  const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p), b = *reinterpret_cast<const f32x4_t*>(p + 4);
+  const f32x3_t c = *reinterpret_cast<const f32x3_t*>(p + 8);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+  v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  v[8] = c[0]; v[9] = c[1]; v[10] = c[2];
+}
 
 struct TuckerShared {
   double coef[TQS * 4][EV];   // [q][evaluation]; row 135 is zero
@@ -68,16 +91,11 @@ __device__ __forceinline__ void tucker_coef(TuckerShared& sh, const ParT& par, c
 }
 
 // Matrix-core phase (after tucker_coef): leaves acc[mb][r] = x_hat of evaluation (lane>>4) + 4r at column
-// 16*(11*wave + mb) + (lane&15).
+// tcol0(wave) + 11*(lane&15) + mb.
 __device__ __forceinline__ void tucker_mfma(TuckerShared& sh, const float* __restrict__ Wm, int tid, f64x4 (&acc)[MBW]) {
   const int lane = tid & 63, wv = tid >> 6;
   const int kq = lane >> 4, col = lane & 15;
-  // column of this lane in block mb: 16*(11*wv + mb) + col.  One base pointer + immediate offsets (64 B per
-  // block); only the very last block (wave 7, block 10) reaches past column 1403: those lanes re-read 1403
-  // (their x_hat is never used).
-  const float* wbase = Wm + 16 * (MBW * wv) + col;
-  const int last_off = (16 * (MBW * wv + MBW - 1) + col < TM) ? 16 * (MBW - 1) : (TM - 1) - (16 * MBW * wv + col);
-  auto woff = [&](int mb) { return mb < MBW - 1 ? 16 * mb : last_off; };
+  const float* wbase = Wm + tcol0(wv) + MBW * col;     // this lane's 11 consecutive columns; always inside the row
 #pragma unroll
   for (int mb = 0; mb < MBW; ++mb) acc[mb] = f64x4{0.0, 0.0, 0.0, 0.0};
   auto row_off = [&](int qs) {   // K step qs reads row 4*qs + kq; the padding row 135 re-reads row 134 (coefficient 0)
@@ -86,18 +104,10 @@ __device__ __forceinline__ void tucker_mfma(TuckerShared& sh, const float* __res
   };
   float wr[TRING][MBW];
 #pragma unroll
-  for (int d = 0; d < TRING - 1; ++d) {
-    const size_t ro = row_off(d);
-#pragma unroll
-    for (int mb = 0; mb < MBW; ++mb) wr[d][mb] = wbase[ro + woff(mb)];
-  }
-  // 34 K steps = 11 groups of 3 + 1: ring slot = step % 3, static inside the unrolled group
+  for (int d = 0; d < TRING - 1; ++d) load11(wbase + row_off(d), wr[d]);
+  // 34 K steps in groups of TRING: ring slot = step % TRING, static inside the unrolled group
   auto step = [&](int qs, int slot, bool prefetch) {
-    if (prefetch) {
-      const size_t ro = row_off(qs + TRING - 1 < TQS ? qs + TRING - 1 : TQS - 1);
-#pragma unroll
-      for (int mb = 0; mb < MBW; ++mb) wr[(slot + TRING - 1) % TRING][mb] = wbase[ro + woff(mb)];
-    }
+    if (prefetch) load11(wbase + row_off(qs + TRING - 1 < TQS ? qs + TRING - 1 : TQS - 1), wr[(slot + TRING - 1) % TRING]);
     const double a = sh.coef[4 * qs + kq][col];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -124,36 +134,43 @@ __device__ __forceinline__ void tucker_xhat(TuckerShared& sh, const float* __res
 // NE (1..4) evaluations on the vector ALUs in ONE pass over Wm, bit-identical to what the matrix-core path leaves in
 // sh.red[.][e] for them (after tucker_coef; the caller's barrier makes red visible).  Used by the Powell kernel when
 // only a few of a workgroup's 16 machines are still running: the MFMA pass costs the same for 1 live evaluation as
-// for 16, and either way a round cannot be shorter than streaming Wm (758 KB) through one CU (~11 us).
+// for 16, and either way a round cannot be shorter than streaming Wm (758 KB) through one CU.
 //   x_hat[m]  the same q-ascending fma chain from +0.0 that one MFMA output accumulates (the padded q = 135
 //             step adds 0 * w and is skipped);
-//   residual  lane (wave w, column group c = lane & 15) owns the columns 16*(11w + mb) + c, mb = 0..10: the four
-//             16-lane quarters of the wave split the 11 blocks (quarter j takes mb = j, j+4, j+8), the differences
-//             are gathered back by shuffles and squared-and-summed in ascending mb order, then the same xor butterfly.
+//   columns   lane L of wave w takes the three consecutive columns tcol0(w) + 3L .. + 2 (lanes 0..58): one 12-byte load per
+//             row, 704 contiguous bytes per wave -- a third of the load instructions of the one-dword-per-block form;
+//   residual  the differences go through `few` (LDS) so that lane c < 16 can square-and-sum the eleven columns
+//             tcol0(w) + 11c .. + 10 in ascending order exactly as the MFMA path's lane c does, then the same xor butterfly.
+struct TuckerFewShared {
+  double d[4][TNW][TWC];       // residuals x - x_hat of up to 4 evaluations, by wave and column-in-wave
+};
+
 template <int NE>
-__device__ __attribute__((noinline)) void tucker_few(TuckerShared& sh, const float* __restrict__ Wm,
-                                           const float* (&xe)[NE], const int (&ev)[NE], int tid) {
-  const int lane = tid & 63, wv = tid >> 6, col = lane & 15, j = lane >> 4;
-  int mc[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int mb = j + 4 * i;                                   // quarter 3 has no third block: it recomputes mb 7
-    const int m = 16 * (MBW * wv + (mb < MBW ? mb : MBW - 4)) + col;
-    mc[i] = m < TM ? m : TM - 1;
-  }
+__device__ __attribute__((noinline)) void tucker_few(TuckerShared& sh, TuckerFewShared& few, const float* __restrict__ Wm,
+                                                     const float* (&xe)[NE], const int (&ev)[NE], int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+  // lanes 0..57 own columns 3L .. 3L+2; lane 58 loads 173..175 and owns 174, 175; lanes 59..63 repeat lane 58's loads, own nothing
+  const int c0 = 3 * lane < TWC - 3 ? 3 * lane : TWC - 3;
+  const int own0 = 3 * lane < TWC ? 3 * lane : TWC;              // first column this lane writes
+  const float* wb = Wm + tcol0(wv) + c0;
   double acc[3][NE];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int n = 0; n < NE; ++n) acc[i][n] = 0.0;
   // Wm streams through registers fifteen rows at a time (45 dwords per lane in flight, 92 KB per CU)
-  constexpr int QB = 15;
-  static_assert(TQ % QB == 0, "135 = 9 x 15");
+#ifndef K3_FEW_QB
+#define K3_FEW_QB 15
+#endif
+  constexpr int QB = K3_FEW_QB;
+  static_assert(TQ % QB == 0, "135 = 9 x 15 = 5 x 27 = 3 x 45");
   float w[2][QB][3];
+  auto load3 = [&](int q, float (&dst)[3]) {
+    const f32x3_t t = *reinterpret_cast<const f32x3_t*>(wb + (size_t)q * TM);
+    dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2];
+  };
 #pragma unroll
-  for (int qq = 0; qq < QB; ++qq)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) w[0][qq][i] = Wm[(size_t)qq * TM + mc[i]];
+  for (int qq = 0; qq < QB; ++qq) load3(qq, w[0][qq]);
 #pragma unroll 1
   for (int qb = 0; qb < TQ / QB; qb += 2) {
 #pragma unroll
@@ -162,9 +179,7 @@ __device__ __attribute__((noinline)) void tucker_few(TuckerShared& sh, const flo
       if (q0 < TQ) {
         const int qn = q0 + QB < TQ ? q0 + QB : q0;             // next block (the last one re-reads itself)
 #pragma unroll
-        for (int qq = 0; qq < QB; ++qq)
-#pragma unroll
-          for (int i = 0; i < 3; ++i) w[half ^ 1][qq][i] = Wm[(size_t)(qn + qq) * TM + mc[i]];
+        for (int qq = 0; qq < QB; ++qq) load3(qn + qq, w[half ^ 1][qq]);
 #pragma unroll
         for (int qq = 0; qq < QB; ++qq)
 #pragma unroll
@@ -177,20 +192,24 @@ __device__ __attribute__((noinline)) void tucker_few(TuckerShared& sh, const flo
     }
   }
 #pragma unroll
-  for (int n = 0; n < NE; ++n) {
-    double d[3];
+  for (int n = 0; n < NE; ++n)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) d[i] = (double)xe[n][mc[i]] - acc[i][n];
-    double s = 0.0;
+    for (int i = 0; i < 3; ++i)
+      if (c0 + i >= own0) few.d[n][wv][c0 + i] = (double)xe[n][tcol0(wv) + c0 + i] - acc[i][n];
+  __syncthreads();
+  if (lane < 16) {
 #pragma unroll
-    for (int mb = 0; mb < MBW; ++mb) {
-      const double dv = __shfl(d[mb >> 2], ((mb & 3) << 4) | col, 64);
-      const bool live = 16 * (MBW * wv + mb) + col < TM;
-      s = live ? fma(dv, dv, s) : s;
+    for (int n = 0; n < NE; ++n) {
+      double s = 0.0;
+#pragma unroll
+      for (int mb = 0; mb < MBW; ++mb) {
+        const double dv = few.d[n][wv][MBW * lane + mb];
+        s = tcol_live(wv, lane, mb) ? fma(dv, dv, s) : s;
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
+      if (lane == 0) sh.red[wv][ev[n]] = s;
     }
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) sh.red[wv][ev[n]] = s;
   }
 }
 
@@ -202,7 +221,7 @@ __device__ __forceinline__ void tucker_residual(TuckerShared& sh, const float (&
   double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int mb = 0; mb < MBW; ++mb) {
-    const bool live = 16 * (MBW * wv + mb) + col < TM;
+    const bool live = tcol_live(wv, col, mb);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const double d = (double)xv[mb][r] - acc[mb][r];
@@ -216,6 +235,11 @@ __device__ __forceinline__ void tucker_residual(TuckerShared& sh, const float (&
     if (col == 0) sh.red[wv][(lane >> 4) + 4 * r] = s[r];
   }
   __syncthreads();
+}
+
+// this lane's eleven x values of a row (the columns of its accumulators): xv[mb] = xrow[tcol0(wave) + 11*(lane&15) + mb]
+__device__ __forceinline__ void tucker_load_x(const float* __restrict__ xrow, int tid, float (&v)[MBW]) {
+  load11(xrow + tcol0(tid >> 6) + MBW * (tid & 15), v);
 }
 
 __device__ __forceinline__ double tucker_err(const TuckerShared& sh, int e) {

@@ -28,7 +28,10 @@ __device__ __attribute__((noinline)) bool powell_step_call(PowellState* s, doubl
 
 // at most this many live machines: evaluate them on the vector ALUs (tucker_few), ~19 us a round against ~36 us for an
 // MFMA round; measured on BASELINE config 3: 4 -> 0.153 s, 8 -> 0.163 s, MFMA only -> 0.242 s
-constexpr int PW_FEW = 4;
+#ifndef PW_FEW_N
+#define PW_FEW_N 4
+#endif
+constexpr int PW_FEW = PW_FEW_N;
 
 struct LdsPar {
   const double (*p)[PW_N];
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
 
   // this lane's 4 evaluations x 11 columns of the feature rows are re-read from L2 every round (44 dwords
   // per lane against 374 of Wm): holding them across the state-machine code costs more in spills
-  const int lane = tid & 63, wv = tid >> 6, col = lane & 15;
+  const int lane = tid & 63;
   const float* xrow[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -106,15 +109,14 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
         }
       }
       __syncthreads();
-      continue;
-    }
-
+    } else {   // NLML_TD_ORDER_FAST (discarded in the other instantiation: its LDS is the reference pass's)
+    __shared__ __attribute__((aligned(16))) TuckerFewShared few;
     tucker_coef(sh, lp, cp4, tid);
-    if (__popc(live_mask) <= PW_FEW) {
+    if (PW_FEW > 0 && __popc(live_mask) <= PW_FEW) {
       // the tail of a workgroup's run: one to a few machines left (a face that needs 6,000 evaluations next to fifteen
       // that needed 1,500).  Their evaluations share ONE pass over Wm on the vector ALUs, bit-identical to the MFMA pass.
-      int ev[PW_FEW];
-      const float* xe[PW_FEW];
+      int ev[PW_FEW > 0 ? PW_FEW : 1];
+      const float* xe[PW_FEW > 0 ? PW_FEW : 1];
       int ne = 0;
       for (int mleft = live_mask; mleft; mleft &= mleft - 1) {
         const int e = __ffs(mleft) - 1;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
     int ek[K];                                                            \
     const float* xk[K];                                                   \
     for (int i = 0; i < K; ++i) { ek[i] = ev[i]; xk[i] = xe[i]; }         \
-    tucker_few<K>(sh, Wm, xk, ek, tid);                                   \
+    tucker_few<K>(sh, few, Wm, xk, ek, tid);                              \
     break;                                                                \
   }
       switch (ne) {
@@ -143,12 +145,12 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
       tucker_mfma(sh, Wm, tid, acc);
       float xv[MBW][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r) {
+        float v[MBW];
+        tucker_load_x(xrow[r], tid, v);
 #pragma unroll
-        for (int mb = 0; mb < MBW; ++mb) {
-          const int m = 16 * (MBW * wv + mb) + col;
-          xv[mb][r] = xrow[r][m < TM ? m : TM - 1];
-        }
+        for (int mb = 0; mb < MBW; ++mb) xv[mb][r] = v[mb];
+      }
       tucker_residual(sh, xv, acc, tid);
     }
 
@@ -161,6 +163,7 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
       }
     }
     __syncthreads();
+    }   // order
   }
 
   if (tid < EV && e0 + tid < N) {

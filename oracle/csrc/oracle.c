@@ -106,16 +106,18 @@ void oracle_encoder_heads_f32(const float* x, int64_t B, int F, const float* con
  * tucker_powell.hip): the MFMA tiling's order, see residual_device_order; the result is then bit-identical to the
  * GPU's, which lets the device-side Powell run be replayed exactly on the CPU. */
 static double residual_device_order(const float* xrow, const double* acc) {
-  /* tucker_common.h: 8 waves x 11 blocks of 16 columns; lane column c of wave w sums its 11 columns
-   * (fma chain, ascending block), xor butterfly over the 16 lanes (offsets 1,2,4,8), then the 8 waves. */
+  /* tucker_common.h: 8 waves x 176 columns from tcol0(w) = 176 w (the last wave: 1228; its first 4 columns belong to wave 6 and
+   * are skipped); lane column c of wave w sums its 11 CONSECUTIVE columns tcol0 + 11 c + mb (fma chain, mb ascending), xor
+   * butterfly over the 16 lanes (offsets 1,2,4,8), then the 8 waves. */
   double red[8];
   for (int w = 0; w < 8; ++w) {
+    const int base = w < 7 ? 176 * w : 1404 - 176;
     double v[16], n[16];
     for (int c = 0; c < 16; ++c) {
       double s = 0.0;
       for (int mb = 0; mb < 11; ++mb) {
-        const int m = 16 * (11 * w + mb) + c;
-        if (m < 1404) { const double r = (double)xrow[m] - acc[m]; s = fma(r, r, s); }
+        const int m = base + 11 * c + mb;
+        if (w < 7 || 11 * c + mb >= 8 * 176 - 1404) { const double r = (double)xrow[m] - acc[m]; s = fma(r, r, s); }
       }
       v[c] = s;
     }

@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 art = weights.load_tucker_artefacts("outputs/features")
 Wm = torch.from_numpy(art["W"].reshape(135, 1404)).to(dev)
 cp = torch.from_numpy(np.stack([art["optimized_yaw"][:3], art["optimized_pitch"][:3], art["optimized_roll"][:3]])).to(dev)
-for N in (4096, 65536):
+for N in (256, 2048, 4096, 8192, 16384, 65536):
     P = torch.from_numpy(synth.tucker_params(N)).to(dev)
     X = torch.from_numpy(synth.features(N, 1404, 3)).to(dev)
     for _ in range(3): ops.tucker_objective(Wm, X, P, cp)
