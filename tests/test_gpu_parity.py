@@ -992,3 +992,24 @@ def test_ops_follow_the_tensors_device(head_sds):
     assert out1.device == d1 and torch.equal(out1.cpu(), out0.cpu())
     with pytest.raises(_lib.NlmlError):
         ops.encoder_heads_fwd(torch.from_numpy(x).to(d0), blob1, 136)
+
+
+def test_video_entry_point_shards_streams_over_ranks(repo_root, device, tmp_path):
+    """BASELINE config 5 at N > 1: two ranks (one-GPU rehearsal: gloo, shared device) each carry a contiguous block of the 64
+    streams; the collated output equals the single-process run bit for bit (streams are independent; no per-tick exchange)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=repo_root)
+    one = subprocess.run([sys.executable, "generatePose_on_video.py", "--source", "synthetic", "--save_output", "True",
+                          "--output_path", str(tmp_path / "one.npz")], cwd=repo_root, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env2 = dict(env, NLML_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    port = 29700 + (os.getpid() % 200)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), "generatePose_on_video.py", "--source", "synthetic", "--save_output", "True",
+                          "--output_path", str(tmp_path / "two.npz")], cwd=repo_root, env=env2, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, (two.stdout[-2000:], two.stderr[-3000:])
+    assert "[rank 1/2, streams 32..63]" in two.stdout
+    a, b = np.load(tmp_path / "one.npz"), np.load(tmp_path / "two.npz")
+    for k in ("smoothed_deg", "endpoints", "valid"):
+        assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
