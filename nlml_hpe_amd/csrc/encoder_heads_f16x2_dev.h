@@ -295,9 +295,11 @@ __device__ __forceinline__ void store_lds(const f32x16 (&acc)[NB][NFB], char* ou
           }
 #endif
         }
-        __builtin_amdgcn_sched_barrier(0);
-        hook((nb * NFB + fb) * 2 + p);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!std::is_same<Hook, NoHook>::value) {   // pin the fetches between the groups; without a hook the
+          __builtin_amdgcn_sched_barrier(0);                 // scheduler is free to overlap the groups' dependency chains
+          hook((nb * NFB + fb) * 2 + p);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
 }
 
