@@ -122,7 +122,7 @@ __device__ __forceinline__ void step_fine(f32x16 (&acc)[NB][NFB], const h8 (&wcu
     for (int i = 0; i < I; ++i) {
       if ((i * M) / I != m) continue;                       // item i lives in slot floor(i * M / I)
       if (i < 2 * NFB) xload(i >> 1, i & 1);                // x operand (face block, piece) of the next step
-      else if (prefetch) wnext[(i - 2 * NFB) >> 1][(i - 2 * NFB) & 1] = wp[(i - 2 * NFB) * 64];
+      else if (prefetch) wnext[(i - 2 * NFB) >> 1][(i - 2 * NFB) & 1] = wp[(i - 2 * NFB) * 64];   // (non-temporal: 70 M instead of 81 M)
     }
     extra(m);
     __builtin_amdgcn_sched_barrier(0);
