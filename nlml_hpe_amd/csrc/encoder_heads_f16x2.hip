@@ -11,15 +11,18 @@
 // the f64 oracle is ~1e-5 degree, like the f32 kernel's (tests/test_gpu_parity.py, tests/studies/
 // split_precision_study.py).  Three 32-cycle f16 MFMAs replace eight 64-cycle f32 MFMAs per 16 k values, so
 // the matrix pipe has 5.3x less work for the same operand bytes (4 per weight, 4 per activation).  Measured:
-// 75 M faces/s fused at B = 65,536 (2.65x the f32 kernel), at the board's power limit.
+// 80 M faces/s fused at B = 65,536 (2.8x the f32 kernel), at the board's power limit.
 //
-// Range: activations above 65504 do not fit f16; hi becomes inf, lo -inf, and the pose of that face comes out
-// NaN (never a silently wrong number).  f16 subnormal pieces are kept by the MFMA (tools/probes/
-// mfma_f16_probe.hip), so small values lose nothing beyond an absolute 2^-25.
+// Range: activations of 65520 and more do not fit f16; hi becomes inf, lo -inf and the MFMA path yields NaN for that
+// face -- which the tile then re-evaluates in f32 on the vector ALUs from the same blob (encoder_heads_f16x2_rescue.h),
+// so there is no input-range limit.  f16 subnormal pieces are kept by the MFMA (tools/probes/mfma_f16_probe.hip), so small
+// values lose nothing beyond an absolute 2^-25.
 //
 // Structure: 64-face tiles, 4 waves; layer 0 in two passes of 512 neurons interleaved with the two K halves
 // of layer 1 (as in the f32 kernel: the 1024-wide layer-0 output of 64 faces is 256 KB in hi+lo f16);
-// x is staged f32 -> (optional f64 IPD normalisation) -> hi/lo f16 through three rotating 32-column LDS slabs.
+// x is staged f32 -> (optional f64 IPD normalisation) -> hi/lo f16 through three rotating 32-column LDS slabs; every K step
+// issues ONE MFMA per slot with the step's fetches and the staging pieces spread behind them (step_fine); a stage's global
+// fetches ride in the previous stage's epilogue; the heads run one at a time over both face blocks (encoder_heads_f16x2_dev.h).
 #include <hip/hip_runtime.h>
 
 #include "../../include/nlml_hpe.h"
