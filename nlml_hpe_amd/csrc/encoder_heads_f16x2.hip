@@ -42,11 +42,16 @@ __device__ __forceinline__ double div_ipd(double n, double d, double y) {
 }
 
 // ------------------------------------------------------------------------------------------
-// One pass of layer 0: x[64,F] f32 -> (optional IPD normalisation in f64) -> hi/lo f16 -> three rotating LDS
-// slabs of 32 columns; this wave computes 128 neurons (4 blocks, job 4*pass + wave) for both face blocks.
+// Layer 0 in ONE pass over x: x[64,F] f32 -> (optional IPD normalisation in f64) -> hi/lo f16 -> three rotating LDS slabs of
+// 32 columns, staged ONCE per face; per K step this wave runs BOTH of its jobs -- neurons 128w.. (job w, accA) and 512+128w..
+// (job 4+w, accB), 4 blocks x 2 face blocks each -- on the same x operands: 256 accumulators per lane = the whole AGPR file,
+// which is why layer 1's accumulators do not exist yet (the caller stores accA, runs layer 1's first K half, then accB).
+// Until round 2 this was two passes over x (one per job): the staging (global loads, normalisation, split, LDS writes) ran
+// twice per face and cost 12 % of the launch (no-staging ablation); jobs, blob and per-accumulator MFMA order are unchanged,
+// so the results are bit-identical to the two-pass form (which the layer-per-launch path still computes).
 template <bool VEC4, bool NORM>
-__device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64_t row0, int tid, int pass,
-                                              f32x16 (&acc)[4][2]) {
+__device__ __forceinline__ void stage_e0(const Ctx& c, const Args& a, int64_t row0, int tid, f32x16 (&accA)[4][2],
+                                         f32x16 (&accB)[4][2]) {
   constexpr int NB = 4, NFB = 2;
   const int F = a.F;
   const int nslab = (int)c.hdr.k8_e0 / XS_STEPS;   // even (pack.cpp)
@@ -97,6 +102,10 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
 #pragma unroll
     for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(st.v[e]));
   };
+  // The six f64 instructions per element (8 issue cycles each) are NOT hidden behind the f16 MFMAs the way f32 VALU work is
+  // (stage stamps: layer 0 takes 195 k cycles with them and 168 k without, whether an element sits behind one MFMA or is cut in
+  // two halves behind two): 7.5 % of a tile is the price of reproducing the reference's f64 division bit for bit in the
+  // fused path.
   auto lw_norm = [&](Set& st, int q) {   // element q (static)
     const int t = q % 3;
     const double rr = t == 0 ? ra : (t == 1 ? rb : rc);
@@ -132,9 +141,12 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
     lw_store(buf_off, 1);
   };
 
-  const int job = 4 * pass + c.wv;
-  load_bias<NB, NFB>(acc, c.blob4 + c.hdr.b_off(ST_E0) + job * (NB * 8), c.h);
-  const h8* w = c.blob8 + c.hdr.w_off(ST_E0) + (size_t)job * c.hdr.job_w16(ST_E0) + c.lane;
+  load_bias<NB, NFB>(accA, c.blob4 + c.hdr.b_off(ST_E0) + c.wv * (NB * 8), c.h);
+  load_bias<NB, NFB>(accB, c.blob4 + c.hdr.b_off(ST_E0) + (4 + c.wv) * (NB * 8), c.h);
+  const h8* wA = c.blob8 + c.hdr.w_off(ST_E0) + (size_t)c.wv * c.hdr.job_w16(ST_E0) + c.lane;
+  const h8* wB = wA + (size_t)4 * c.hdr.job_w16(ST_E0);
+  // the weight stream in consumption order: half-step hs = 2 * (K step) + (0: job A, 1: job B)
+  auto wfrag = [&](int hs) { return ((hs & 1) ? wB : wA) + (size_t)(hs >> 1) * (NB * 2 * 64); };
 
   // TWO staging register sets (8 floats per thread each), one per slab parity: slab s+2 is written to LDS during
   // slab s from set[s & 1], which is refilled at once with the loads of slab s+4.  vmcnt counts in issue
@@ -142,8 +154,8 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
   // (4 K steps, 32 weight loads) lie between its loads and its use, and in the prologue the sets are loaded BEFORE
   // the weight ring so that the loop header sees the same distance on entry as on the back edge.
   Set set[2];
-  constexpr int R0 = 4, D0 = R0 - 1;   // weight ring: K step ks in slot ks % 4 = 2*(slab & 1) + step of the slab
-  static_assert(2 * XS_STEPS == R0, "two slabs == ring slots");
+  constexpr int R0 = 4, D0 = R0 - 1;   // weight ring: half-step hs in slot hs % 4 = 2 * (step of the slab) + job
+  static_assert(2 * XS_STEPS == R0, "one slab == four half-steps == ring slots");
   h8 wr[R0][NB][2];
   gload(0, set[0]);
   gload(1, set[1]);
@@ -156,7 +168,7 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int pp = 0; pp < 2; ++pp) wr[d][nb][pp] = w[((d * NB + nb) * 2 + pp) * 64];
+      for (int pp = 0; pp < 2; ++pp) wr[d][nb][pp] = wfrag(d)[(nb * 2 + pp) * 64];
   __syncthreads();
 
   const int lane_off = (c.f * S_XS + 8 * c.h) * 2;   // bytes
@@ -175,31 +187,34 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
     const bool real = s + 2 < nslab;
 #pragma unroll
     for (int kk = 0; kk < XS_STEPS; ++kk) {
-      const int slot = 2 * PAR + kk;
-      step_fine<NB, NFB>(acc, wr[slot], xr[kk & 1], wr[(slot + D0) % R0], w + (size_t)(s * XS_STEPS + kk + D0) * (NB * 2 * 64), true,
-              [&](int fb, int pp) {
-                xr[(kk + 1) & 1][fb][pp] = (kk + 1 < XS_STEPS)
-                                               ? *reinterpret_cast<const h8*>(xrow + pp * P_XS + fb * FB + 32 * (kk + 1))
-                                               : *reinterpret_cast<const h8*>(xnext + pp * P_XS + fb * FB);
-              },
-              [&](int m) {   // slab s+2's staging in the step's free (odd) slots: step 0 normalises, step 1 splits, stores, reloads
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int slot = 2 * kk + half;                       // == half-step % 4: a slab is exactly one turn of the ring
+        const int hs = 2 * (s * XS_STEPS + kk) + half;
+        step_fine<NB, NFB>(half ? accB : accA, wr[slot], xr[kk & 1], wr[(slot + D0) % R0], wfrag(hs + D0), true,
+                [&](int fb, int pp) {                         // the next K step's x operands, fetched during job A's half
+                  if (half) return;
+                  xr[(kk + 1) & 1][fb][pp] = (kk + 1 < XS_STEPS)
+                                                 ? *reinterpret_cast<const h8*>(xrow + pp * P_XS + fb * FB + 32 * (kk + 1))
+                                                 : *reinterpret_cast<const h8*>(xnext + pp * P_XS + fb * FB);
+                },
+                [&](int m) {   // slab s+2's staging in the free (odd) slots of the slab's four half-steps
 #ifdef HX_ABL_NOSTAGE
-                return;      // timing-only ablation (wrong results)
+                  return;      // timing-only ablation (wrong results)
 #endif
-                if ((m & 1) == 0) return;
-                const int j = m >> 1;                        // free slot 0..11 of this step
-                if (kk == 0) {
+                  if ((m & 1) == 0) return;
+                  const int j = 12 * slot + (m >> 1);          // free slot 0..47 of this slab
+                  // 48 free slots per slab: 8 normalisations, rotate, 4 splits, 2 LDS stores, 2 reloads
                   if (j == 0) lw_begin(set[PAR]);
-                  if (NORM && j >= 1 && j <= 8) lw_norm(set[PAR], j - 1);
-                  if (NORM && j == 9) lw_rotate();
-                } else {
-                  if (j < 4) lw_split(set[PAR], j, real);
-                  if (j == 4) lw_store(o2, 0);
-                  if (j == 5) lw_store(o2, 1);
-                  if (j == 6) gload_half(s + 4, set[PAR], 0);
-                  if (j == 7) gload_half(s + 4, set[PAR], 1);
-                }
-              });
+                  if (NORM && j >= 2 && j < 18 && (j & 1) == 0) lw_norm(set[PAR], (j - 2) >> 1);
+                  if (NORM && j == 18) lw_rotate();
+                  if (j >= 24 && j < 32 && (j & 1) == 0) lw_split(set[PAR], (j - 24) >> 1, real);
+                  if (j == 32) lw_store(o2, 0);
+                  if (j == 34) lw_store(o2, 1);
+                  if (j == 36) gload_half(s + 4, set[PAR], 0);
+                  if (j == 38) gload_half(s + 4, set[PAR], 1);
+                });
+      }
     }
 #ifndef HX_ABL_NOBAR
     __syncthreads();
@@ -211,7 +226,7 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
     slab(s, std::integral_constant<int, 0>{});
     slab(s + 1, std::integral_constant<int, 1>{});
   }
-  if (pass == 0 && a.valid) {  // all-zero feature row == "no face" (FeatureExtractor.py:105-106); 4 lanes share a row
+  if (a.valid) {  // all-zero feature row == "no face" (FeatureExtractor.py:105-106); 4 lanes share a row
     const unsigned long long m = __ballot(nzbits != 0u);
     if ((tid & 3) == 0 && live) a.valid[row0 + srow] = ((m >> (c.lane & 60)) & 0xFull) ? 1 : 0;
   }
@@ -237,30 +252,34 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
 
   f32x16 acc2[2][2];
   h8 wr2[ring_slots(2, 2)][2][2];
-  {  // E0 (two passes of 512 neurons) interleaved with the two K halves of E1
+  {  // E0 (one pass over x, both neuron halves) then the two K halves of E1
     f32x16 acc1[4][2];
-    load_bias<4, 2>(acc1, c.blob4 + c.hdr.b_off(ST_E1) + wv * (4 * 8), c.h);
     const h8* w1 = c.blob8 + c.hdr.w_off(ST_E1) + (size_t)wv * c.hdr.job_w16(ST_E1) + c.lane;
     const float inv0 = c.hdr.inv_scale[ST_E0];
     HXS(0);
     HXS_WALL(30);
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      {
-        f32x16 acc0[4][2];
-        stage_e0_pass<VEC4, NORM>(c, a, row0, tid, pass, acc0);
-        HXS(1 + 4 * pass);
-        // the last barrier of the slab loop also says: every wave is done reading H1H (previous pass's E1 half)
-        job_store<4, 2, ACT_RELU>(c, acc0, O_H1H, P_H1H, S_H1H, 128 * wv, 0, inv0);
-      }
+    {
+      f32x16 acc0a[4][2], acc0b[4][2];
+      stage_e0<VEC4, NORM>(c, a, row0, tid, acc0a, acc0b);
+      HXS(1);
+      // layer 1's accumulators start to exist here (bias): until now layer 0 held every accumulator register
+      load_bias<4, 2>(acc1, c.blob4 + c.hdr.b_off(ST_E1) + wv * (4 * 8), c.h);
+      job_store<4, 2, ACT_RELU>(c, acc0a, O_H1H, P_H1H, S_H1H, 128 * wv, 0, inv0);
       __syncthreads();
-      HXS(2 + 4 * pass);
-      kloop<4, 2, 32>(acc1, w1 + (size_t)pass * 32 * (4 * 2 * 64), c.lds + O_H1H + (c.f * S_H1H + 8 * c.h) * 2, P_H1H,
-                      32 * S_H1H * 2);
-      HXS(3 + 4 * pass);
-      __syncthreads();   // H1H is free again (pass 0: for pass 1's store; pass 1: for H2)
-      HXS(4 + 4 * pass);
+      HXS(2);
+      kloop<4, 2, 32>(acc1, w1, c.lds + O_H1H + (c.f * S_H1H + 8 * c.h) * 2, P_H1H, 32 * S_H1H * 2);
+      HXS(3);
+      __syncthreads();   // H1H is free again: for the second half of layer 0's output
+      HXS(4);
+      job_store<4, 2, ACT_RELU>(c, acc0b, O_H1H, P_H1H, S_H1H, 128 * wv, 0, inv0);
     }
+    __syncthreads();
+    HXS(5);
+    kloop<4, 2, 32>(acc1, w1 + (size_t)32 * (4 * 2 * 64), c.lds + O_H1H + (c.f * S_H1H + 8 * c.h) * 2, P_H1H, 32 * S_H1H * 2);
+    HXS(6);
+    __syncthreads();     // H1H is free again: for H2
+    HXS(7);
+    HXS(8);
     // E2's global fetches (bias, first ring slots) ride in E1's epilogue (store_lds hook, encoder_heads_f16x2_dev.h)
     job_store<4, 2, ACT_RELU>(c, acc1, O_H2, P_H2, S_H2, 128 * wv, 0, c.hdr.inv_scale[ST_E1],
                               fetch_hook<16, 2, 2, ST_E2>(c, wv, acc2, wr2));

@@ -19,7 +19,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 tiles = B // 64
 st = lat.cpu().numpy().reshape(-1).view(np.uint64)[: tiles * 4 * 32].reshape(tiles, 4, 32).astype(np.int64)
-names = ["E0a slabs", "E0a store+bar", "E1a kloop", "E1a bar", "E0b slabs", "E0b store+bar", "E1b kloop", "E1b bar",
+names = ["E0 slabs (one pass)", "E0a store+bar", "E1a kloop", "E1a bar", "E0b store+bar", "E1b kloop", "E1b bar", "-",
          "h2 store+bar", "E2", "E3", "E4+E5", "H0 yaw", "H1 yaw", "H2-H4 yaw", "H0 pitch", "H1 pitch", "H2-H4 pitch",
          "H0 roll", "H1 roll", "H2-H4 roll"]
 NS = len(names) + 1                                   # stamps 0 .. 21
@@ -27,7 +27,7 @@ d = np.diff(st[:, :, :NS], axis=2).astype(np.float64)
 tot = (st[:, :, NS - 1] - st[:, :, 0]).astype(np.float64)
 print(f"{path}: tiles {tiles}  mean cycles/tile (wave avg) {tot.mean():,.0f}  min {tot.min():,.0f} max {tot.max():,.0f}")
 M = 32 * 3   # cycles per (nb, fb, K16) product = three 32-cycle MFMAs
-ideal = {"E0a slabs": 88 * 8 * M, "E0b slabs": 88 * 8 * M, "E1a kloop": 32 * 8 * M, "E1b kloop": 32 * 8 * M, "E2": 32 * 4 * M,
+ideal = {"E0 slabs (one pass)": 88 * 16 * M, "E1a kloop": 32 * 8 * M, "E1b kloop": 32 * 8 * M, "E2": 32 * 4 * M,
          "E3": 16 * 2 * M, "E4+E5": (8 + 4 * 2) * M}
 for h in ("yaw", "pitch", "roll"):                    # one head, 64 faces: per wave H0 1x2, H1 8 steps x 2x2, H2 16 x 1x2, H3 8 x 1x1, H4 4 x 1x1
     ideal[f"H0 {h}"] = 2 * M
@@ -36,7 +36,7 @@ for h in ("yaw", "pitch", "roll"):                    # one head, 64 faces: per 
 for i, n in enumerate(names):
     m = d[:, :, i].mean()
     extra = f"  ideal MFMA {ideal[n]:,}  ({ideal[n]/m*100:.0f}% busy)" if n in ideal else ""
-    print(f"{n:16s} {m:10,.0f} cyc  {m/tot.mean()*100:5.1f}%{extra}")
+    print(f"{n:20s} {m:10,.0f} cyc  {m/tot.mean()*100:5.1f}%{extra}")
 g0 = st[:, :, [12, 22, 23, 24, 25, 13, 26, 27, 28, 14]].astype(np.float64)          # the yaw head's first two stages in detail
 for n, v in zip(["H0 pre issued", "H0 run", "H1 pre issued", "H0 store", "barrier", "H1 run", "H2 pre issued", "H1 store", "barrier"],
                 np.diff(g0, axis=2).mean(axis=(0, 1))):
