@@ -262,6 +262,14 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
       f32x16 acc0a[4][2], acc0b[4][2];
       stage_e0<VEC4, NORM>(c, a, row0, tid, acc0a, acc0b);
       HXS(1);
+      // acc0b (128 registers) has to survive layer 1's first K half next to layer 1's 128 accumulators: the AGPR file is full
+      // and the compiler spilled one tile of it to scratch -- sixteen reloads, each waited for on its own (11.7 k cycles for
+      // this store in the fused kernel against 5.2 k without the spill).  The x slabs' LDS region is free from here on: one
+      // tile is parked there by hand (four 16-byte LDS stores and loads per lane).
+      f32x4* stash = reinterpret_cast<f32x4*>(c.lds + O_XS) + tid * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        stash[q] = f32x4{acc0b[3][1][4 * q], acc0b[3][1][4 * q + 1], acc0b[3][1][4 * q + 2], acc0b[3][1][4 * q + 3]};
       // layer 1's accumulators start to exist here (bias): until now layer 0 held every accumulator register
       load_bias<4, 2>(acc1, c.blob4 + c.hdr.b_off(ST_E1) + wv * (4 * 8), c.h);
       job_store<4, 2, ACT_RELU>(c, acc0a, O_H1H, P_H1H, S_H1H, 128 * wv, 0, inv0);
@@ -271,7 +279,13 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
       HXS(3);
       __syncthreads();   // H1H is free again: for the second half of layer 0's output
       HXS(4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 t = stash[q];
+        acc0b[3][1][4 * q] = t[0]; acc0b[3][1][4 * q + 1] = t[1]; acc0b[3][1][4 * q + 2] = t[2]; acc0b[3][1][4 * q + 3] = t[3];
+      }
       job_store<4, 2, ACT_RELU>(c, acc0b, O_H1H, P_H1H, S_H1H, 128 * wv, 0, inv0);
+      HXS(29);
     }
     __syncthreads();
     HXS(5);

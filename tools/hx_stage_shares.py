@@ -41,6 +41,8 @@ g0 = st[:, :, [12, 22, 23, 24, 25, 13, 26, 27, 28, 14]].astype(np.float64)      
 for n, v in zip(["H0 pre issued", "H0 run", "H1 pre issued", "H0 store", "barrier", "H1 run", "H2 pre issued", "H1 store", "barrier"],
                 np.diff(g0, axis=2).mean(axis=(0, 1))):
     print(f"   yaw detail: {n:16s} {v:8,.0f} cyc")
+print(f"   E0b detail: store {np.mean(st[:, :, 29] - st[:, :, 4]):,.0f} cyc, barrier wait {np.mean(st[:, :, 5] - st[:, :, 29]):,.0f} cyc "
+      f"(per wave: store {[int(v) for v in np.mean(st[:, :, 29] - st[:, :, 4], axis=0)]}, wait {[int(v) for v in np.mean(st[:, :, 5] - st[:, :, 29], axis=0)]})")
 wall = (st[:, :, 31] - st[:, :, 30]).astype(np.float64)      # 100 MHz ticks
 print(f"core clock during a tile: {tot.mean() / (wall.mean() * 10.0):.3f} GHz (s_memtime / s_memrealtime); tile wall time {wall.mean()*0.01:.1f} us; "
       f"first start {st[:, :, 30].min()}, last end {st[:, :, 31].max()} -> kernel span {(st[:, :, 31].max() - st[:, :, 30].min())*0.01:.1f} us")
