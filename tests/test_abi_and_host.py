@@ -147,3 +147,13 @@ def test_mode_names_and_default_are_the_parity_modes():
     assert default in (_lib.MODE_F16X2, _lib.MODE_F32), "the default must be one of the two parity modes, never bf16"
     with pytest.raises(_lib.NlmlError):
         M.HIPPoseModel(synth.encoder_state_dict(136, 0), weights.load_head_state_dicts("models"), device="cpu")
+
+
+def test_mode_and_order_names():
+    assert _lib.mode_from_name("f16x2") == _lib.MODE_F16X2 and _lib.mode_from_name(0) == _lib.MODE_F32
+    assert _lib.td_order_from_name("reference") == _lib.TD_ORDER_REFERENCE and _lib.td_order_from_name(0) == _lib.TD_ORDER_FAST
+    for bad in ("fp8", 7):
+        with pytest.raises(ValueError):
+            _lib.mode_from_name(bad)
+        with pytest.raises(ValueError):
+            _lib.td_order_from_name(bad)
