@@ -145,32 +145,43 @@ struct TuckerFewShared {
   double d[4][TNW][TWC];       // residuals x - x_hat of up to 4 evaluations, by wave and column-in-wave
 };
 
+#ifndef K3_FEW_CPL
+#define K3_FEW_CPL 4
+#endif
 template <int NE>
 __device__ __attribute__((noinline)) void tucker_few(TuckerShared& sh, TuckerFewShared& few, const float* __restrict__ Wm,
                                                      const float* (&xe)[NE], const int (&ev)[NE], int tid) {
   const int lane = tid & 63, wv = tid >> 6;
-  // lanes 0..57 own columns 3L .. 3L+2; lane 58 loads 173..175 and owns 174, 175; lanes 59..63 repeat lane 58's loads, own nothing
-  const int c0 = 3 * lane < TWC - 3 ? 3 * lane : TWC - 3;
-  const int own0 = 3 * lane < TWC ? 3 * lane : TWC;              // first column this lane writes
+  // CPL consecutive columns per lane: with 4, lanes 0..43 own columns 4L .. 4L+3 and every load is an ALIGNED 16-byte load (rows
+  // are 5,616 B = 351 x 16, the wave bases 704 w and 4,912 B too); with 3, lanes 0..58 and 12-byte loads at 12-byte strides.
+  constexpr int CPL = K3_FEW_CPL;
+  static_assert(TWC % CPL == 0 || CPL == 3, "columns per lane");
+  const int c0 = CPL * lane < TWC - CPL ? CPL * lane : TWC - CPL;   // lanes beyond the last owner repeat its loads
+  const int own0 = CPL * lane < TWC ? CPL * lane : TWC;              // first column this lane writes
   const float* wb = Wm + tcol0(wv) + c0;
-  double acc[3][NE];
+  double acc[CPL][NE];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < CPL; ++i)
 #pragma unroll
     for (int n = 0; n < NE; ++n) acc[i][n] = 0.0;
-  // Wm streams through registers fifteen rows at a time (45 dwords per lane in flight, 92 KB per CU)
+  // Wm streams through registers fifteen rows at a time
 #ifndef K3_FEW_QB
 #define K3_FEW_QB 15
 #endif
   constexpr int QB = K3_FEW_QB;
   static_assert(TQ % QB == 0, "135 = 9 x 15 = 5 x 27 = 3 x 45");
-  float w[2][QB][3];
-  auto load3 = [&](int q, float (&dst)[3]) {
-    const f32x3_t t = *reinterpret_cast<const f32x3_t*>(wb + (size_t)q * TM);
-    dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2];
+  float w[2][QB][CPL];
+  auto loadc = [&](int q, float (&dst)[CPL]) {
+    if constexpr (CPL == 4) {
+      const f32x4_t t = *reinterpret_cast<const f32x4_t*>(wb + (size_t)q * TM);
+      dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3];
+    } else {
+      const f32x3_t t = *reinterpret_cast<const f32x3_t*>(wb + (size_t)q * TM);
+      dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2];
+    }
   };
 #pragma unroll
-  for (int qq = 0; qq < QB; ++qq) load3(qq, w[0][qq]);
+  for (int qq = 0; qq < QB; ++qq) loadc(qq, w[0][qq]);
 #pragma unroll 1
   for (int qb = 0; qb < TQ / QB; qb += 2) {
 #pragma unroll
@@ -179,14 +190,14 @@ __device__ __attribute__((noinline)) void tucker_few(TuckerShared& sh, TuckerFew
       if (q0 < TQ) {
         const int qn = q0 + QB < TQ ? q0 + QB : q0;             // next block (the last one re-reads itself)
 #pragma unroll
-        for (int qq = 0; qq < QB; ++qq) load3(qn + qq, w[half ^ 1][qq]);
+        for (int qq = 0; qq < QB; ++qq) loadc(qn + qq, w[half ^ 1][qq]);
 #pragma unroll
         for (int qq = 0; qq < QB; ++qq)
 #pragma unroll
           for (int n = 0; n < NE; ++n) {
             const double c = sh.coef[q0 + qq][ev[n]];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) acc[i][n] = fma(c, (double)w[half][qq][i], acc[i][n]);
+            for (int i = 0; i < CPL; ++i) acc[i][n] = fma(c, (double)w[half][qq][i], acc[i][n]);
           }
       }
     }
@@ -194,7 +205,7 @@ __device__ __attribute__((noinline)) void tucker_few(TuckerShared& sh, TuckerFew
 #pragma unroll
   for (int n = 0; n < NE; ++n)
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < CPL; ++i)
       if (c0 + i >= own0) few.d[n][wv][c0 + i] = (double)xe[n][tcol0(wv) + c0 + i] - acc[i][n];
   __syncthreads();
   if (lane < 16) {
@@ -211,6 +222,63 @@ __device__ __attribute__((noinline)) void tucker_few(TuckerShared& sh, TuckerFew
       if (lane == 0) sh.red[wv][ev[n]] = s;
     }
   }
+}
+
+// Up to FOUR evaluations on v_mfma_f64_4x4x4_4b_f64 (the Powell kernel's rounds with 2..4 live machines).  That instruction
+// (tools/probes/mfma_f64_4x4_probe.hip) has the 16x16x4 form's B and D lane maps restricted to four rows -- lane l supplies
+// B[k = l>>4][column l&15] and receives D[evaluation l>>4][column l&15] -- takes A[evaluation l&3][k = l>>4], is the same
+// k-ascending fma chain and issues in 17 cycles instead of 64: a pass over Wm for <= 4 evaluations costs a quarter of the matrix
+// time of tucker_mfma and, unlike the vector-ALU pass (+3.7 us per machine), does not grow with the number of live machines.
+// Same columns per lane, same chains, same reduction tree => the same bits as tucker_mfma + tucker_residual.
+// ev[i] / xe[i], i < 4: machine slot and x row of evaluation i (entries at and beyond `ne` repeat a live one; not stored).
+__device__ __attribute__((noinline)) void tucker_mfma4(TuckerShared& sh, const float* __restrict__ Wm, const float* const (&xe)[4],
+                                                       const int (&ev)[4], int ne, int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+  const int kq = lane >> 4, col = lane & 15;
+  const int ia = lane & 3;                                   // the evaluation whose coefficient this lane feeds (A operand)
+  const int eva = ia == 0 ? ev[0] : (ia == 1 ? ev[1] : (ia == 2 ? ev[2] : ev[3]));
+  const float* wbase = Wm + tcol0(wv) + MBW * col;
+  double acc[MBW];
+#pragma unroll
+  for (int mb = 0; mb < MBW; ++mb) acc[mb] = 0.0;
+  auto row_off = [&](int qs) {
+    const int q = 4 * qs + kq;
+    return (size_t)(q < TQ ? q : TQ - 1) * TM;
+  };
+  float wr[TRING][MBW];
+#pragma unroll
+  for (int d = 0; d < TRING - 1; ++d) load11(wbase + row_off(d), wr[d]);
+  auto step = [&](int qs, int slot, bool prefetch) {
+    if (prefetch) load11(wbase + row_off(qs + TRING - 1 < TQS ? qs + TRING - 1 : TQS - 1), wr[(slot + TRING - 1) % TRING]);
+    const double a = sh.coef[4 * qs + kq][eva];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb)
+      acc[mb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, (double)wr[slot][mb], acc[mb], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  constexpr int GROUPS = TQS / TRING, TAIL = TQS % TRING;
+  for (int g = 0; g < GROUPS; ++g) {
+#pragma unroll
+    for (int r = 0; r < TRING; ++r) step(g * TRING + r, r, true);
+  }
+#pragma unroll
+  for (int r = 0; r < TAIL; ++r) step(GROUPS * TRING + r, r, false);
+  // residual of evaluation id = lane >> 4 over this lane's eleven columns, then the butterfly over the 16 column lanes
+  const int id = kq;
+  const float* xrow = id == 0 ? xe[0] : (id == 1 ? xe[1] : (id == 2 ? xe[2] : xe[3]));
+  const int evd = id == 0 ? ev[0] : (id == 1 ? ev[1] : (id == 2 ? ev[2] : ev[3]));
+  float xv[MBW];
+  load11(xrow + tcol0(wv) + MBW * col, xv);
+  double s = 0.0;
+#pragma unroll
+  for (int mb = 0; mb < MBW; ++mb) {
+    const double d = (double)xv[mb] - acc[mb];
+    s = tcol_live(wv, col, mb) ? fma(d, d, s) : s;
+  }
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
+  if (col == 0 && id < ne) sh.red[wv][evd] = s;
 }
 
 // Residual norms of the 16 evaluations.  xv[mb][r] = x of evaluation (lane>>4) + 4r at this lane's column of

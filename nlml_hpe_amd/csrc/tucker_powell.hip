@@ -88,6 +88,12 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
   __syncthreads();
 
   const LdsPar lp{par};
+#ifdef PW_STAMPS   // timing-only diagnostic: cycles per phase summed over the rounds, written over fval[e0 .. e0+3] at the end
+  unsigned long long ph[4] = {0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime();
+#define PWS(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tp; tp = t_; } while (0)
+#else
+#define PWS(i) do { } while (0)
+#endif
   for (int round = 0; round < PW_N * 1000 + 16; ++round) {
     int live_mask = 0;
 #pragma unroll
@@ -111,7 +117,9 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
       __syncthreads();
     } else {   // NLML_TD_ORDER_FAST (discarded in the other instantiation: its LDS is the reference pass's)
     __shared__ __attribute__((aligned(16))) TuckerFewShared few;
+    PWS(0);
     tucker_coef(sh, lp, cp4, tid);
+    PWS(1);
     if (PW_FEW > 0 && __popc(live_mask) <= PW_FEW) {
       // the tail of a workgroup's run: one to a few machines left (a face that needs 6,000 evaluations next to fifteen
       // that needed 1,500).  Their evaluations share ONE pass over Wm on the vector ALUs, bit-identical to the MFMA pass.
@@ -134,9 +142,19 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
     tucker_few<K>(sh, few, Wm, xk, ek, tid);                              \
     break;                                                                \
   }
+#ifndef PW_MFMA4_FROM
+#define PW_MFMA4_FROM 2          // rounds with this many live machines or more (up to 4) take the 4x4x4 matrix pass
+#endif
+      if (ne >= PW_MFMA4_FROM) {
+        int e4[4];
+        const float* x4[4];
+        for (int i = 0; i < 4; ++i) { e4[i] = ev[i < ne ? i : 0]; x4[i] = xe[i < ne ? i : 0]; }
+        tucker_mfma4(sh, Wm, x4, e4, ne, tid);
+      } else {
       switch (ne) {
         NLML_FEW_CASE(1) NLML_FEW_CASE(2) NLML_FEW_CASE(3) NLML_FEW_CASE(4)
         default: break;   // unreachable: ne <= PW_FEW
+      }
       }
 #undef NLML_FEW_CASE
       __syncthreads();
@@ -154,6 +172,7 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
       tucker_residual(sh, xv, acc, tid);
     }
 
+    PWS(2);
     if (me >= 0 && need[me]) {   // resume the state machines with their objective values
       const bool nd = powell_step_call(&st[me], tucker_err(sh, me));
       need[me] = nd ? 1 : 0;
@@ -163,6 +182,7 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
       }
     }
     __syncthreads();
+    PWS(3);
     }   // order
   }
 
@@ -171,6 +191,9 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
 #pragma unroll
     for (int k = 0; k < PW_N; ++k) result[n * PW_N + k] = st[tid].x[k];
     if (fval) fval[n] = st[tid].fval;
+#ifdef PW_STAMPS
+    if (fval && tid < 4) fval[n] = (double)ph[tid];
+#endif
     if (nfev) nfev[n] = st[tid].nfev;
     if (nit) nit[n] = st[tid].iter;
     if (status) status[n] = need[tid] ? PW_RUNNING : st[tid].status;

@@ -1,0 +1,20 @@
+"""Per-phase cycles of a Powell round from the -DPW_STAMPS diagnostic build.  usage: NLML_HPE_LIB=exp_libs/pw_stamps.so python tools/powell_phases.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from nlml_hpe_amd import ops, synth, weights
+dev = torch.device("cuda:0")
+art = weights.load_tucker_artefacts("outputs/features")
+Wm = torch.from_numpy(art["W"].reshape(135, 1404)).to(dev)
+cp = torch.from_numpy(np.stack([art["optimized_yaw"][:3], art["optimized_pitch"][:3], art["optimized_roll"][:3]])).to(dev)
+idx = synth.tucker_grid_indices(64, seed=2)
+Xg = torch.from_numpy(synth.tucker_grid_faces(art, idx, 1e-3, seed=2)).to(dev)
+for copies in (1, 3, 16):
+    X = Xg[:1].repeat(copies, 1).contiguous()
+    if copies < 4:
+        X = torch.cat([X, Xg[1:5 - copies]])        # pad the workgroup to >= 4 faces so that fval[0..3] exist (the extra faces finish early)
+    res = ops.tucker_powell(Wm, X, cp)
+    torch.cuda.synchronize()
+    ph = res["fun"][:4].cpu().numpy()
+    nf = int(res["nfev"].max())
+    print(f"{copies:2d} long-lived machines, {nf} rounds: cycles per round: live-mask {ph[0]/nf:7.0f}  coefficients {ph[1]/nf:7.0f}  evaluation {ph[2]/nf:7.0f}  state machines + barrier {ph[3]/nf:7.0f}  total {ph.sum()/nf:7.0f}")
