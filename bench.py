@@ -85,6 +85,20 @@ def time_kernel(fn, iters, warm=3):
     return float(np.mean([a.elapsed_time(b) for a, b in evs]))  # ms
 
 
+def time_stream(fn, iters, warm=3):
+    """ms per call of `iters` calls issued back to back (one event pair around all of them)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
 def spawn_ranks(n: int, script: str = None, argv: list = None) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of THIS process, which has not
     touched the GPU (importing torch does not initialise HIP; nothing above calls torch.cuda), wait for them, relay rank 0's
@@ -401,8 +415,17 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     N = 4096
     P = torch.from_numpy(synth.tucker_params(N, 5, seed=2)).to(dev)
     ms = time_kernel(lambda: ops.tucker_objective(Wm, feats[:N], P, cp), 20)
-    ex["k3_tucker_objective"] = {"evals_per_sec": N / ms * 1e3, "tflops_f64": N * TUCKER_FLOP_PER_EVAL / ms / 1e9,
-                                 "f64_frac": N * TUCKER_FLOP_PER_EVAL / ms / 1e9 / PEAK_F64_TFLOPS, "n": N}
+    ms_s = time_stream(lambda: ops.tucker_objective(Wm, feats[:N], P, cp), 20)
+    ex["k3_tucker_objective"] = {"evals_per_sec": N / ms_s * 1e3, "tflops_f64": N * TUCKER_FLOP_PER_EVAL / ms_s / 1e9,
+                                 "f64_frac": N * TUCKER_FLOP_PER_EVAL / ms_s / 1e9 / PEAK_F64_TFLOPS, "n": N,
+                                 "timing": "20 launches back to back between one event pair (a 34-us kernel: an event pair "
+                                           "around every launch adds ~3 us of launch gap to each)",
+                                 "f64_frac_event_pair_per_launch": N * TUCKER_FLOP_PER_EVAL / ms / 1e9 / PEAK_F64_TFLOPS}
+    NL = 65536
+    PL = torch.from_numpy(synth.tucker_params(NL, 5, seed=3)).to(dev)
+    ms_l = time_stream(lambda: ops.tucker_objective(Wm, feats[:NL], PL, cp), 10)
+    ex["k3_tucker_objective_65536"] = {"evals_per_sec": NL / ms_l * 1e3,
+                                       "f64_frac": NL * TUCKER_FLOP_PER_EVAL / ms_l / 1e9 / PEAK_F64_TFLOPS, "n": NL}
     # host-resident batch: pinned staging + copy stream overlapped with compute (PCIe-inclusive; never `value`)
     from nlml_hpe_amd.model import HIPPoseModel
     from nlml_hpe_amd.pipeline import HostPipeline

@@ -9,21 +9,25 @@
 //   err[e]      = 0.5 * sum_m (x[m]-x_hat[m])^2   fixed-order reduction                          (:49)
 //
 // Workgroup = 512 threads = 8 waves; wave w owns the 176 columns from tcol0(w) = 176 w (the last wave: 1228, so that it ends
-// at column 1403; its first four columns repeat wave 6's last four and are ignored) as 11 MFMA column blocks: block mb's MFMA
-// column j is column  tcol0(w) + 11 j + mb  (44 f64 accumulators per lane).  A lane therefore needs ELEVEN CONSECUTIVE floats
-// of a Wm row per K step -- three loads of 16 + 16 + 12 bytes (704 contiguous bytes per row and wave) -- instead of the eleven
-// single-dword loads of the blocks-of-16-consecutive-columns map this kernel started with: those were 256-byte wave
-// instructions, and the CU's address path (one wave-instruction per ~16 cycles), not the matrix pipe, set the pace (a
-// timing-only build with 3 of the 11 loads ran at 66 % of the f64 peak instead of 56 %).  Per K step of 4 a wave reads its A
-// fragment (16 evaluations x 4 coefficients) from LDS once; each row of Wm is read once per workgroup, i.e. once per 16
-// evaluations; f32 -> f64 in the register.  One MFMA (64 cycles) replaces 16 v_fma_f64 wave-instructions (the VALU form of this
-// kernel reached 29 % of the f64 peak).
+// at column 1403; its first four columns repeat wave 6's last four and are ignored) as 11 MFMA column blocks (44 f64
+// accumulators per lane).  Block mb's MFMA column j is the wave's column
+//     tlcol(j, mb) = 64 (mb/4) + 4 j + mb%4      for mb < 8      (two groups of four consecutive columns, 16 B aligned)
+//                  = 128 + 3 j + (mb - 8)         for mb >= 8     (three consecutive columns)
+// so a lane fetches its eleven B operands of a K step with three loads (16 + 16 + 12 bytes) and the 16 lanes of a row read
+// CONTIGUOUS 256 + 256 + 192 bytes: a wave instruction touches 16 sixty-four-byte sectors.  History of this map, each step
+// measured: blocks of 16 consecutive columns (eleven dword loads per lane: 256-byte wave instructions, the CU's address path
+// -- not the matrix pipe -- set the pace: a timing-only build with 3 of the 11 loads ran at 66 % of the f64 peak instead of
+// 56 %); eleven consecutive columns per lane (three loads at a 44-byte lane stride: every instruction touched ~46 sectors and
+// the pass over Wm could not go faster than ~24 B/clk per CU -- the few-machine rounds of the Powell kernel were bound by
+// exactly that); this one.  Per K step of 4 a wave reads its A fragment (16 evaluations x 4 coefficients) from LDS once; each
+// row of Wm is read once per workgroup, i.e. once per 16 evaluations; f32 -> f64 in the register.  One MFMA (64 cycles)
+// replaces 16 v_fma_f64 wave-instructions (the VALU form of this kernel reached 29 % of the f64 peak).
 //
 // MFMA operand / result maps (f64 16x16x4, cdna_hip_programming.md section 3): lane l supplies
 // A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; result register r of lane l is D[(l>>4) + 4r][l&15].
 //
 // Reduction order (the C oracle's device_order mode replays it bit for bit):
-//   lane:  for each of its 4 evaluations, fma chain over its 11 (consecutive) columns in ascending order, dead columns skipped;
+//   lane:  for each of its 4 evaluations, fma chain over its 11 columns tlcol(j, mb), mb ascending, dead columns skipped;
 //   wave:  xor butterfly over the 16 lanes of a column group, offsets 1, 2, 4, 8;
 //   block: ((w0+w1)+(w2+w3)) + ((w4+w5)+(w6+w7)); then * 0.5.
 #pragma once
@@ -51,14 +55,23 @@ constexpr int TRING = K3_TRING;         // Wm prefetch ring (K steps)
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x3_t __attribute__((ext_vector_type(3)));
 
-// first column of wave w, and whether (lane column j, block mb) of wave w is a column of its own (wave 7 starts 4 early)
+// first column of wave w; the wave's column of (lane column j, block mb); whether that is a column of its own (wave 7 starts 4 early)
 __host__ __device__ __forceinline__ constexpr int tcol0(int w) { return w < TNW - 1 ? TWC * w : TM - TWC; }
-__host__ __device__ __forceinline__ constexpr bool tcol_live(int w, int j, int mb) { return w < TNW - 1 || MBW * j + mb >= TNW * TWC - TM; }
+__host__ __device__ __forceinline__ constexpr int tlcol(int j, int mb) { return mb < 8 ? 64 * (mb >> 2) + 4 * j + (mb & 3) : 128 + 3 * j + (mb - 8); }
+__host__ __device__ __forceinline__ constexpr bool tcol_live(int w, int j, int mb) { return w < TNW - 1 || tlcol(j, mb) >= TNW * TWC - TM; }
 
-// eleven consecutive floats from p (4-byte aligned): three loads
-__device__ __forceinline__ void load11(const float* __restrict__ p, float (&v)[MBW]) {
-  const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p), b = *reinterpret_cast<const f32x4_t*>(p + 4);
-  const f32x3_t c = *reinterpret_cast<const f32x3_t*>(p + 8);
+// A load from DEVICE-GLOBAL memory through a generic pointer.  Inside a non-inlined device function the compiler cannot see
+// that Wm / x are global and emits flat_load, which counts on lgkmcnt as well as vmcnt: every wait for an LDS read then also
+// waits for the Wm prefetch issued just before it and the prefetch ring hides nothing.  global_load counts on vmcnt alone.
+template <typename T>
+__device__ __forceinline__ T gload(const void* p) {
+  return *(const __attribute__((address_space(1))) T*)p;
+}
+
+// the eleven floats of lane column j from a wave's 176-column row segment p (global memory, 16-byte aligned): v[mb] = p[tlcol(j, mb)]
+__device__ __forceinline__ void load11(const float* __restrict__ p, int j, float (&v)[MBW]) {
+  const f32x4_t a = gload<f32x4_t>(p + 4 * j), b = gload<f32x4_t>(p + 64 + 4 * j);
+  const f32x3_t c = gload<f32x3_t>(p + 128 + 3 * j);
   v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
   v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
   v[8] = c[0]; v[9] = c[1]; v[10] = c[2];
@@ -91,11 +104,11 @@ __device__ __forceinline__ void tucker_coef(TuckerShared& sh, const ParT& par, c
 }
 
 // Matrix-core phase (after tucker_coef): leaves acc[mb][r] = x_hat of evaluation (lane>>4) + 4r at column
-// tcol0(wave) + 11*(lane&15) + mb.
+// tcol0(wave) + tlcol(lane&15, mb).
 __device__ __forceinline__ void tucker_mfma(TuckerShared& sh, const float* __restrict__ Wm, int tid, f64x4 (&acc)[MBW]) {
   const int lane = tid & 63, wv = tid >> 6;
   const int kq = lane >> 4, col = lane & 15;
-  const float* wbase = Wm + tcol0(wv) + MBW * col;     // this lane's 11 consecutive columns; always inside the row
+  const float* wbase = Wm + tcol0(wv);                 // the wave's 176-column segment; always inside the row
 #pragma unroll
   for (int mb = 0; mb < MBW; ++mb) acc[mb] = f64x4{0.0, 0.0, 0.0, 0.0};
   auto row_off = [&](int qs) {   // K step qs reads row 4*qs + kq; the padding row 135 re-reads row 134 (coefficient 0)
@@ -104,10 +117,10 @@ __device__ __forceinline__ void tucker_mfma(TuckerShared& sh, const float* __res
   };
   float wr[TRING][MBW];
 #pragma unroll
-  for (int d = 0; d < TRING - 1; ++d) load11(wbase + row_off(d), wr[d]);
+  for (int d = 0; d < TRING - 1; ++d) load11(wbase + row_off(d), col, wr[d]);
   // 34 K steps in groups of TRING: ring slot = step % TRING, static inside the unrolled group
   auto step = [&](int qs, int slot, bool prefetch) {
-    if (prefetch) load11(wbase + row_off(qs + TRING - 1 < TQS ? qs + TRING - 1 : TQS - 1), wr[(slot + TRING - 1) % TRING]);
+    if (prefetch) load11(wbase + row_off(qs + TRING - 1 < TQS ? qs + TRING - 1 : TQS - 1), col, wr[(slot + TRING - 1) % TRING]);
     const double a = sh.coef[4 * qs + kq][col];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -140,11 +153,14 @@ __device__ __forceinline__ void tucker_xhat(TuckerShared& sh, const float* __res
 //   columns   lane L of wave w takes the three consecutive columns tcol0(w) + 3L .. + 2 (lanes 0..58): one 12-byte load per
 //             row, 704 contiguous bytes per wave -- a third of the load instructions of the one-dword-per-block form;
 //   residual  the differences go through `few` (LDS) so that lane c < 16 can square-and-sum the eleven columns
-//             tcol0(w) + 11c .. + 10 in ascending order exactly as the MFMA path's lane c does, then the same xor butterfly.
+//             tcol0(w) + tlcol(c, mb), mb ascending, exactly as the MFMA path's lane c does, then the same xor butterfly.
 struct TuckerFewShared {
   double d[4][TNW][TWC];       // residuals x - x_hat of up to 4 evaluations, by wave and column-in-wave
 };
 
+#ifndef K3_TRING4
+#define K3_TRING4 3          // ring depth of the 4x4x4 pass (tucker_mfma4)
+#endif
 #ifndef K3_FEW_CPL
 #define K3_FEW_CPL 4
 #endif
@@ -173,10 +189,10 @@ __device__ __attribute__((noinline)) void tucker_few(TuckerShared& sh, TuckerFew
   float w[2][QB][CPL];
   auto loadc = [&](int q, float (&dst)[CPL]) {
     if constexpr (CPL == 4) {
-      const f32x4_t t = *reinterpret_cast<const f32x4_t*>(wb + (size_t)q * TM);
+      const f32x4_t t = gload<f32x4_t>(wb + (size_t)q * TM);
       dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3];
     } else {
-      const f32x3_t t = *reinterpret_cast<const f32x3_t*>(wb + (size_t)q * TM);
+      const f32x3_t t = gload<f32x3_t>(wb + (size_t)q * TM);
       dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2];
     }
   };
@@ -206,7 +222,7 @@ __device__ __attribute__((noinline)) void tucker_few(TuckerShared& sh, TuckerFew
   for (int n = 0; n < NE; ++n)
 #pragma unroll
     for (int i = 0; i < CPL; ++i)
-      if (c0 + i >= own0) few.d[n][wv][c0 + i] = (double)xe[n][tcol0(wv) + c0 + i] - acc[i][n];
+      if (c0 + i >= own0) few.d[n][wv][c0 + i] = (double)gload<float>(xe[n] + tcol0(wv) + c0 + i) - acc[i][n];
   __syncthreads();
   if (lane < 16) {
 #pragma unroll
@@ -214,7 +230,7 @@ __device__ __attribute__((noinline)) void tucker_few(TuckerShared& sh, TuckerFew
       double s = 0.0;
 #pragma unroll
       for (int mb = 0; mb < MBW; ++mb) {
-        const double dv = few.d[n][wv][MBW * lane + mb];
+        const double dv = few.d[n][wv][tlcol(lane, mb)];
         s = tcol_live(wv, lane, mb) ? fma(dv, dv, s) : s;
       }
 #pragma unroll
@@ -237,7 +253,7 @@ __device__ __attribute__((noinline)) void tucker_mfma4(TuckerShared& sh, const f
   const int kq = lane >> 4, col = lane & 15;
   const int ia = lane & 3;                                   // the evaluation whose coefficient this lane feeds (A operand)
   const int eva = ia == 0 ? ev[0] : (ia == 1 ? ev[1] : (ia == 2 ? ev[2] : ev[3]));
-  const float* wbase = Wm + tcol0(wv) + MBW * col;
+  const float* wbase = Wm + tcol0(wv);
   double acc[MBW];
 #pragma unroll
   for (int mb = 0; mb < MBW; ++mb) acc[mb] = 0.0;
@@ -245,31 +261,37 @@ __device__ __attribute__((noinline)) void tucker_mfma4(TuckerShared& sh, const f
     const int q = 4 * qs + kq;
     return (size_t)(q < TQ ? q : TQ - 1) * TM;
   };
-  float wr[TRING][MBW];
+  // The f32 -> f64 conversion sits right before its MFMA: converting a step ahead between the matrix instructions was measured
+  // slower -- on gfx950 nothing issues in the shadow of an f64 MFMA (tools/probes/mfma_f64_shadow_probe.hip: every vector
+  // instruction next to one adds its own issue time), so a pass costs (MFMA + conversion) x 374 per wave whatever the order.
+  constexpr int R4 = K3_TRING4;
+  float wr[R4][MBW];
 #pragma unroll
-  for (int d = 0; d < TRING - 1; ++d) load11(wbase + row_off(d), wr[d]);
+  for (int d = 0; d < R4 - 1; ++d) load11(wbase + row_off(d), col, wr[d]);
+  double a = sh.coef[kq][eva];
   auto step = [&](int qs, int slot, bool prefetch) {
-    if (prefetch) load11(wbase + row_off(qs + TRING - 1 < TQS ? qs + TRING - 1 : TQS - 1), wr[(slot + TRING - 1) % TRING]);
-    const double a = sh.coef[4 * qs + kq][eva];
+    if (prefetch) load11(wbase + row_off(qs + R4 - 1 < TQS ? qs + R4 - 1 : TQS - 1), col, wr[(slot + R4 - 1) % R4]);
+    const double an = sh.coef[4 * (qs + 1 < TQS ? qs + 1 : qs) + kq][eva];   // next step's coefficient: its LDS latency hides here
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mb = 0; mb < MBW; ++mb)
       acc[mb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, (double)wr[slot][mb], acc[mb], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    a = an;
   };
-  constexpr int GROUPS = TQS / TRING, TAIL = TQS % TRING;
+  constexpr int GROUPS = TQS / R4, TAIL = TQS % R4;
   for (int g = 0; g < GROUPS; ++g) {
 #pragma unroll
-    for (int r = 0; r < TRING; ++r) step(g * TRING + r, r, true);
+    for (int r = 0; r < R4; ++r) step(g * R4 + r, r, true);
   }
 #pragma unroll
-  for (int r = 0; r < TAIL; ++r) step(GROUPS * TRING + r, r, false);
+  for (int r = 0; r < TAIL; ++r) step(GROUPS * R4 + r, r, false);
   // residual of evaluation id = lane >> 4 over this lane's eleven columns, then the butterfly over the 16 column lanes
   const int id = kq;
   const float* xrow = id == 0 ? xe[0] : (id == 1 ? xe[1] : (id == 2 ? xe[2] : xe[3]));
   const int evd = id == 0 ? ev[0] : (id == 1 ? ev[1] : (id == 2 ? ev[2] : ev[3]));
   float xv[MBW];
-  load11(xrow + tcol0(wv) + MBW * col, xv);
+  load11(xrow + tcol0(wv), col, xv);
   double s = 0.0;
 #pragma unroll
   for (int mb = 0; mb < MBW; ++mb) {
@@ -305,9 +327,9 @@ __device__ __forceinline__ void tucker_residual(TuckerShared& sh, const float (&
   __syncthreads();
 }
 
-// this lane's eleven x values of a row (the columns of its accumulators): xv[mb] = xrow[tcol0(wave) + 11*(lane&15) + mb]
+// this lane's eleven x values of a row (the columns of its accumulators): xv[mb] = xrow[tcol0(wave) + tlcol(lane&15, mb)]
 __device__ __forceinline__ void tucker_load_x(const float* __restrict__ xrow, int tid, float (&v)[MBW]) {
-  load11(xrow + tcol0(tid >> 6) + MBW * (tid & 15), v);
+  load11(xrow + tcol0(tid >> 6), tid & 15, v);
 }
 
 __device__ __forceinline__ double tucker_err(const TuckerShared& sh, int e) {

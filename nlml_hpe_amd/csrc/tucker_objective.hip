@@ -62,7 +62,7 @@ __global__ __launch_bounds__(TNT, 2) void tucker_objective_kernel(
     for (int mb = 0; mb < MBW; ++mb) {
       xv[mb][r] = v[mb];
 #ifndef K3_STAMPS
-      if (x_hat && live && tcol_live(wv, col, mb)) x_hat[n * TM + tcol0(wv) + MBW * col + mb] = acc[mb][r];
+      if (x_hat && live && tcol_live(wv, col, mb)) x_hat[n * TM + tcol0(wv) + tlcol(col, mb)] = acc[mb][r];
 #endif
     }
   }

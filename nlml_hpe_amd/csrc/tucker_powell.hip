@@ -24,7 +24,9 @@ namespace nlml {
 
 // The state machine is a large switch; inlined into the kernel it inflates the register demand of the
 // whole function (spills in the MFMA loop).  As a real call its registers are its own.
-__device__ __attribute__((noinline)) bool powell_step_call(PowellState* s, double f) { return powell_step(*s, f); }
+// The state is passed as an LDS pointer: through a generic one every access to it would be a flat_load / flat_store.
+typedef __attribute__((address_space(3))) PowellState LdsPowellState;
+__device__ __attribute__((noinline)) bool powell_step_call(LdsPowellState* s, double f) { return powell_step(*(PowellState*)s, f); }
 
 // at most this many live machines: evaluate them on the vector ALUs (tucker_few), ~19 us a round against ~36 us for an
 // MFMA round; measured on BASELINE config 3: 4 -> 0.153 s, 8 -> 0.163 s, MFMA only -> 0.242 s
@@ -32,6 +34,27 @@ __device__ __attribute__((noinline)) bool powell_step_call(PowellState* s, doubl
 #define PW_FEW_N 4
 #endif
 constexpr int PW_FEW = PW_FEW_N;
+
+// A round with many live machines: all 16 evaluations on the 16x16x4 matrix cores, exactly K3's body.  Not inlined, like the
+// few-machine passes: its 150 registers are then allocated on their own instead of across the state-machine code (inlined, the
+// fully unrolled MFMA loop spilled).  The lane's 4 evaluations x 11 columns of the feature rows are re-read from L2 every round
+// (44 dwords per lane against 374 of Wm).
+__device__ __attribute__((noinline)) void tucker_round16(TuckerShared& sh, const float* __restrict__ Wm, const float* __restrict__ x,
+                                                         int64_t ldx, int64_t e0, int64_t N, int tid) {
+  f64x4 acc[MBW];
+  tucker_mfma(sh, Wm, tid, acc);
+  float xv[MBW][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int64_t n = e0 + ((tid & 63) >> 4) + 4 * r;
+    n = n < N ? n : N - 1;
+    float v[MBW];
+    tucker_load_x(x + n * ldx, tid, v);
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb) xv[mb][r] = v[mb];
+  }
+  tucker_residual(sh, xv, acc, tid);
+}
 
 struct LdsPar {
   const double (*p)[PW_N];
@@ -54,16 +77,6 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
   const int tid = threadIdx.x;
   const int64_t e0 = (int64_t)blockIdx.x * EV;
 
-  // this lane's 4 evaluations x 11 columns of the feature rows are re-read from L2 every round (44 dwords
-  // per lane against 374 of Wm): holding them across the state-machine code costs more in spills
-  const int lane = tid & 63;
-  const float* xrow[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    int64_t n = e0 + (lane >> 4) + 4 * r;
-    n = n < N ? n : N - 1;
-    xrow[r] = x + n * ldx;
-  }
   double cp4[4] = {0, 0, 0, 0};
   if (tid < EV * 9) {
     const double* c4 = cosp + ((tid % 9) / 3 * 3 + tid % 3) * 4;
@@ -80,7 +93,7 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
 #pragma unroll
     for (int k = 0; k < PW_N; ++k) z[k] = (x0 && live) ? x0[(e0 + me) * PW_N + k] : 0.0;
     powell_init(st[me], z);
-    const bool nd = live && powell_step_call(&st[me], 0.0);
+    const bool nd = live && powell_step_call((LdsPowellState*)&st[me], 0.0);
     need[me] = nd ? 1 : 0;
 #pragma unroll
     for (int k = 0; k < PW_N; ++k) par[me][k] = st[me].xeval[k];
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
                       [&](int slot) { int64_t n = e0 + slot; n = n < N ? n : N - 1; return x + n * ldx; },
                       [&](int) { return (double*)nullptr; }, tid);
       if (me >= 0 && need[me]) {
-        const bool nd = powell_step_call(&st[me], rs.err[me]);
+        const bool nd = powell_step_call((LdsPowellState*)&st[me], rs.err[me]);
         need[me] = nd ? 1 : 0;
         if (nd) {
 #pragma unroll
@@ -159,22 +172,12 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
 #undef NLML_FEW_CASE
       __syncthreads();
     } else {
-      f64x4 acc[MBW];
-      tucker_mfma(sh, Wm, tid, acc);
-      float xv[MBW][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v[MBW];
-        tucker_load_x(xrow[r], tid, v);
-#pragma unroll
-        for (int mb = 0; mb < MBW; ++mb) xv[mb][r] = v[mb];
-      }
-      tucker_residual(sh, xv, acc, tid);
+      tucker_round16(sh, Wm, x, ldx, e0, N, tid);
     }
 
     PWS(2);
     if (me >= 0 && need[me]) {   // resume the state machines with their objective values
-      const bool nd = powell_step_call(&st[me], tucker_err(sh, me));
+      const bool nd = powell_step_call((LdsPowellState*)&st[me], tucker_err(sh, me));
       need[me] = nd ? 1 : 0;
       if (nd) {
 #pragma unroll

@@ -80,7 +80,7 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
 #pragma unroll
         for (int l = 0; l < 3; ++l)
 #pragma unroll
-          for (int c = 0; c < TR_COLS; ++c) w[l][c] = Wm[(size_t)(q0 + l) * TM + mc[c]];
+          for (int c = 0; c < TR_COLS; ++c) w[l][c] = gload<float>(Wm + (size_t)(q0 + l) * TM + mc[c]);
 #pragma unroll
         for (int l = 0; l < 3; ++l) {
 #pragma unroll
@@ -105,7 +105,7 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
 #pragma unroll
     for (int c = 0; c < TR_COLS; ++c)
       if (livec[c]) {
-        const double d = (double)xe[n][mc[c]] - acc[c][n];
+        const double d = (double)gload<float>(xe[n] + mc[c]) - acc[c][n];
         rs.d2[n][mc[c]] = d * d;
         if (xh[n]) xh[n][mc[c]] = acc[c][n];
       }

@@ -107,8 +107,9 @@ void oracle_encoder_heads_f32(const float* x, int64_t B, int F, const float* con
  * GPU's, which lets the device-side Powell run be replayed exactly on the CPU. */
 static double residual_device_order(const float* xrow, const double* acc) {
   /* tucker_common.h: 8 waves x 176 columns from tcol0(w) = 176 w (the last wave: 1228; its first 4 columns belong to wave 6 and
-   * are skipped); lane column c of wave w sums its 11 CONSECUTIVE columns tcol0 + 11 c + mb (fma chain, mb ascending), xor
-   * butterfly over the 16 lanes (offsets 1,2,4,8), then the 8 waves. */
+   * are skipped); lane column c of wave w sums its 11 columns tcol0 + tlcol(c, mb) (fma chain, mb ascending), where
+   * tlcol(c, mb) = 64 (mb/4) + 4 c + mb%4 for mb < 8 and 128 + 3 c + (mb - 8) above; xor butterfly over the 16 lanes (offsets
+   * 1,2,4,8), then the 8 waves. */
   double red[8];
   for (int w = 0; w < 8; ++w) {
     const int base = w < 7 ? 176 * w : 1404 - 176;
@@ -116,8 +117,9 @@ static double residual_device_order(const float* xrow, const double* acc) {
     for (int c = 0; c < 16; ++c) {
       double s = 0.0;
       for (int mb = 0; mb < 11; ++mb) {
-        const int m = base + 11 * c + mb;
-        if (w < 7 || 11 * c + mb >= 8 * 176 - 1404) { const double r = (double)xrow[m] - acc[m]; s = fma(r, r, s); }
+        const int lc = mb < 8 ? 64 * (mb >> 2) + 4 * c + (mb & 3) : 128 + 3 * c + (mb - 8);
+        const int m = base + lc;
+        if (w < 7 || lc >= 8 * 176 - 1404) { const double r = (double)xrow[m] - acc[m]; s = fma(r, r, s); }
       }
       v[c] = s;
     }
