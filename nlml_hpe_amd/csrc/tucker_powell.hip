@@ -28,8 +28,8 @@ namespace nlml {
 typedef __attribute__((address_space(3))) PowellState LdsPowellState;
 __device__ __attribute__((noinline)) bool powell_step_call(LdsPowellState* s, double f) { return powell_step(*(PowellState*)s, f); }
 
-// at most this many live machines: evaluate them on the vector ALUs (tucker_few), ~19 us a round against ~36 us for an
-// MFMA round; measured on BASELINE config 3: 4 -> 0.153 s, 8 -> 0.163 s, MFMA only -> 0.242 s
+// at most this many live machines: a few-machine pass instead of the 16-wide one -- 13 us (one machine, vector ALUs) or 15 us
+// (2..4, 4x4x4 matrix instruction) a round against 30 us; BASELINE config 3 end to end: 0.120 s, 16-wide rounds only 0.24 s
 #ifndef PW_FEW_N
 #define PW_FEW_N 4
 #endif
