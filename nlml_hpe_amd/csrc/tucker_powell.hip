@@ -101,6 +101,16 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
   __syncthreads();
 
   const LdsPar lp{par};
+  // live machines as one word per round parity: the machines that want another evaluation OR their bit into the next round's
+  // word (sixteen LDS reads per thread and round before)
+  __shared__ int livew[2];
+  if (tid == 0) {
+    int m0 = 0;
+    for (int e = 0; e < EV; ++e) m0 |= need[e] << e;
+    livew[0] = m0;
+    livew[1] = 0;
+  }
+  __syncthreads();
 #ifdef PW_STAMPS   // timing-only diagnostic: cycles per phase summed over the rounds, written over fval[e0 .. e0+3] at the end
   unsigned long long ph[4] = {0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime();
 #define PWS(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tp; tp = t_; } while (0)
@@ -108,10 +118,9 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
 #define PWS(i) do { } while (0)
 #endif
   for (int round = 0; round < PW_N * 1000 + 16; ++round) {
-    int live_mask = 0;
-#pragma unroll
-    for (int e = 0; e < EV; ++e) live_mask |= need[e] << e;
+    const int live_mask = livew[round & 1];
     if (!live_mask) break;
+    if (tid == 0) livew[(round + 1) & 1] = 0;     // last read a round ago; the barriers of the evaluation order this before the ORs below
 
     if constexpr (ORDER == NLML_TD_ORDER_REFERENCE) {
       __shared__ __attribute__((aligned(16))) TuckerRefShared rs;
@@ -123,6 +132,7 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
         const bool nd = powell_step_call((LdsPowellState*)&st[me], rs.err[me]);
         need[me] = nd ? 1 : 0;
         if (nd) {
+          atomicOr(&livew[(round + 1) & 1], 1 << me);
 #pragma unroll
           for (int k = 0; k < PW_N; ++k) par[me][k] = st[me].xeval[k];
         }
@@ -180,6 +190,7 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
       const bool nd = powell_step_call((LdsPowellState*)&st[me], tucker_err(sh, me));
       need[me] = nd ? 1 : 0;
       if (nd) {
+        atomicOr(&livew[(round + 1) & 1], 1 << me);
 #pragma unroll
         for (int k = 0; k < PW_N; ++k) par[me][k] = st[me].xeval[k];
       }
