@@ -29,7 +29,7 @@ typedef __attribute__((address_space(3))) PowellState LdsPowellState;
 __device__ __attribute__((noinline)) bool powell_step_call(LdsPowellState* s, double f) { return powell_step(*(PowellState*)s, f); }
 
 // at most this many live machines: a few-machine pass instead of the 16-wide one -- 13 us (one machine, vector ALUs) or 15 us
-// (2..4, 4x4x4 matrix instruction) a round against 30 us; BASELINE config 3 end to end: 0.120 s, 16-wide rounds only 0.24 s
+// (2..4, 4x4x4 matrix instruction) a round against 30 us; BASELINE config 3 end to end: 0.119 s, 16-wide rounds only 0.24 s
 #ifndef PW_FEW_N
 #define PW_FEW_N 4
 #endif
