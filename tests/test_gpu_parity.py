@@ -1013,3 +1013,72 @@ def test_video_entry_point_shards_streams_over_ranks(repo_root, device, tmp_path
     a, b = np.load(tmp_path / "one.npz"), np.load(tmp_path / "two.npz")
     for k in ("smoothed_deg", "endpoints", "valid"):
         assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "f32"])
+def test_batch_beyond_2_31_elements_is_indexed_in_64_bits(mode, head_sds, device):
+    """3,100,000 faces = 4.35e9 input elements (17 GB): every row offset in K1/K2 has to be 64-bit.  A face's result does not
+    depend on its position in the batch, so windows of the big batch (first tile, around the 2^31- and 2^32-element marks, a
+    ragged end) must equal the same faces run as small batches, bit for bit -- validity mask and no-face rows included."""
+    B = 3_100_000
+    free, _ = torch.cuda.mem_get_info(device)
+    if free < 80 * 2**30:
+        pytest.skip("needs ~60 GB of device memory")
+    sd = synth.encoder_state_dict(1404, seed=0)
+    blob = (_blob_hx if mode == "f16x2" else _blob)(sd, head_sds, device)
+    base = synth.raw_landmarks(4096, seed=21)
+    base[::97] = 0.0                                                   # "no face" rows (generatePose_on_video.py:118)
+    base = torch.from_numpy(base).to(device)
+    raw = base.repeat(B // 4096 + 1, 1, 1)[:B].contiguous()           # 4,096 distinct faces tiled to the big batch ...
+    bump = torch.arange(B, device=device, dtype=torch.float32) * 1e-7  # ... and made distinct per position
+    bump[::97] = 0.0                                                   # (B's tiling period 4,096 is not a multiple of 97: recompute)
+    noface = raw.abs().amax(dim=(1, 2)) == 0
+    raw[:, 5, 1] += torch.where(noface, torch.zeros_like(bump), bump + 1e-7)
+    del bump
+    pose, valid = ops.landmarks_to_pose(raw, blob, True, return_valid=True)
+    torch.cuda.synchronize()
+    assert torch.equal(valid, ~noface)
+    mark = 2**31 // 1404                                               # the face at the 2^31-element mark (2^33 bytes)
+    for lo, hi in ((0, 64), (mark // 4 - 64, mark // 4 + 64), (mark - 100, mark + 100), (2 * mark - 70, 2 * mark + 61),
+                   (B - 1000, B), (B - 37, B)):
+        p2, v2 = ops.landmarks_to_pose(raw[lo:hi].contiguous(), blob, True, return_valid=True)
+        assert torch.equal(valid[lo:hi], v2), (lo, hi)
+        a, b = pose[lo:hi].contiguous(), p2
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (mode, lo, hi, float((a - b).abs().max()))
+    assert bool(torch.isfinite(pose[valid]).all())
+    if mode == "f16x2":     # K1 alone and K2 from features at the same size: the two-launch path leaves the fused launch's bits
+        feats = ops.normalize_ipd(raw, True)
+        for lo, hi in ((mark - 100, mark + 100), (2 * mark - 70, 2 * mark + 61), (B - 37, B)):
+            assert torch.equal(feats[lo:hi], ops.normalize_ipd(raw[lo:hi].contiguous(), True)), (lo, hi)
+        pose2 = ops.encoder_heads_fwd(feats, blob, 1404)
+        assert torch.equal(pose2[valid].view(torch.int32), pose[valid].view(torch.int32))
+        del feats, pose2
+    del pose, raw
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("order", ["fast", "reference"])
+def test_tucker_objective_beyond_2_31_elements(order, tucker_art, device):
+    """1,600,000 evaluations on 1,600,000 distinct x rows (2.25e9 elements, 9 GB): row offsets are 64-bit.  Evaluations are
+    independent, so windows around the 2^31-element mark and at the ragged end equal small launches of the same rows, bit for bit
+    -- directly and through x_index."""
+    N = 1_600_000
+    free, _ = torch.cuda.mem_get_info(device)
+    if free < 30 * 2**30:
+        pytest.skip("needs ~20 GB of device memory")
+    cp = torch.from_numpy(_cos_params(tucker_art)).to(device)
+    Wm = torch.from_numpy(tucker_art["W"].reshape(135, 1404)).to(device)
+    base = torch.from_numpy(synth.features(4096, 1404, seed=31)).to(device)
+    X = base.repeat(N // 4096 + 1, 1)[:N].contiguous()
+    X[:, 7] += torch.arange(N, device=device, dtype=torch.float32) * 1e-7
+    P = torch.from_numpy(synth.tucker_params(4096, 5, seed=32)).to(device).repeat(N // 4096 + 1, 1)[:N].contiguous()
+    err = ops.tucker_objective(Wm, X, P, cp, order=order)
+    torch.cuda.synchronize()
+    mark = 2**31 // 1404
+    for lo, hi in ((0, 16), (mark - 50, mark + 50), (N - 1001, N), (N - 5, N)):
+        small = ops.tucker_objective(Wm, X[lo:hi].contiguous(), P[lo:hi].contiguous(), cp, order=order)
+        assert torch.equal(err[lo:hi].view(torch.int64), small.view(torch.int64)), (order, lo, hi)
+        idx = torch.arange(lo, hi, device=device, dtype=torch.int32)
+        via = ops.tucker_objective(Wm, X, P[lo:hi].contiguous(), cp, x_index=idx, order=order)
+        assert torch.equal(via.view(torch.int64), small.view(torch.int64)), (order, lo, hi, "x_index")
+    assert bool(torch.isfinite(err).all())
