@@ -102,14 +102,27 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const Args& a, int64_t ro
 #pragma unroll
     for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(st.v[e]));
   };
-  // The six f64 instructions per element (8 issue cycles each) are NOT hidden behind the f16 MFMAs the way f32 VALU work is
-  // (stage stamps: layer 0 takes 195 k cycles with them and 168 k without, whether an element sits behind one MFMA or is cut in
-  // two halves behind two): 7.5 % of a tile is the price of reproducing the reference's f64 division bit for bit in the
-  // fused path.
+  // Normalisation = six DEPENDENT f64 instructions per element (convert, subtract, multiply, two correction fmas, convert).
+  // Issued as one chain behind one MFMA (the first form) they cost ~77 cycles per element: the chain's latency, ~13 cycles per
+  // link, not its issue time -- tools/probes/mfma_f16_dp_probe.hip shows that up to three INDEPENDENT f64 instructions do hide
+  // in the shadow of a 32x32x16 f16 MFMA.  So the loop form (lw_norm2) gives every free slot ONE link of the chains of TWO
+  // elements: the next link of the same element comes a whole MFMA later.  lw_norm (prologue only) is the plain chain.
   auto lw_norm = [&](Set& st, int q) {   // element q (static)
     const int t = q % 3;
     const double rr = t == 0 ? ra : (t == 1 ? rb : rc);
     st.v[q] = (float)div_ipd((double)st.v[q] - rr, ipd, rcp);
+  };
+  double nA = 0.0, nB = 0.0, qA = 0.0, qB = 0.0;   // the pair in flight
+  auto lw_norm2 = [&](Set& st, int pair, int link) {   // elements 2*pair, 2*pair+1 (static), link 0..5 of div_ipd's chain
+    const int e0 = 2 * pair, e1 = e0 + 1;
+    const double r0 = e0 % 3 == 0 ? ra : (e0 % 3 == 1 ? rb : rc), r1 = e1 % 3 == 0 ? ra : (e1 % 3 == 1 ? rb : rc);
+    // (the empty asm pins each link to its slot: pure arithmetic is otherwise sunk towards its use, back into one cluster)
+    if (link == 0) { nA = (double)st.v[e0]; nB = (double)st.v[e1]; asm volatile("" : "+v"(nA), "+v"(nB)); }
+    if (link == 1) { nA = nA - r0; nB = nB - r1; asm volatile("" : "+v"(nA), "+v"(nB)); }
+    if (link == 2) { qA = nA * rcp; qB = nB * rcp; asm volatile("" : "+v"(qA), "+v"(qB)); }
+    if (link == 3) { nA = fma(-qA, ipd, nA); nB = fma(-qB, ipd, nB); asm volatile("" : "+v"(nA), "+v"(nB)); }
+    if (link == 4) { qA = fma(nA, rcp, qA); qB = fma(nB, rcp, qB); asm volatile("" : "+v"(qA), "+v"(qB)); }
+    if (link == 5) { st.v[e0] = (float)qA; st.v[e1] = (float)qB; asm volatile("" : "+v"(st.v[e0]), "+v"(st.v[e1])); }
   };
   auto lw_rotate = [&]() {   // next slab: columns + 32 => phase + 2
     const double t0 = rc; rc = rb; rb = ra; ra = t0;
@@ -204,15 +217,20 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const Args& a, int64_t ro
 #endif
                   if ((m & 1) == 0) return;
                   const int j = 12 * slot + (m >> 1);          // free slot 0..47 of this slab
-                  // 48 free slots per slab: 8 normalisations, rotate, 4 splits, 2 LDS stores, 2 reloads
+                  // 48 free slots per slab: 24 normalisation links (4 pairs x 6), rotate, 4 splits, 2 LDS stores, 2 reloads
                   if (j == 0) lw_begin(set[PAR]);
+#ifdef HX_NORM_CHAIN   // the first form, kept for A/B timing: one whole element per slot
                   if (NORM && j >= 2 && j < 18 && (j & 1) == 0) lw_norm(set[PAR], (j - 2) >> 1);
                   if (NORM && j == 18) lw_rotate();
-                  if (j >= 24 && j < 32 && (j & 1) == 0) lw_split(set[PAR], (j - 24) >> 1, real);
-                  if (j == 32) lw_store(o2, 0);
-                  if (j == 34) lw_store(o2, 1);
-                  if (j == 36) gload_half(s + 4, set[PAR], 0);
-                  if (j == 38) gload_half(s + 4, set[PAR], 1);
+#else
+                  if (NORM && j < 24) lw_norm2(set[PAR], j / 6, j % 6);
+                  if (NORM && j == 24) lw_rotate();
+#endif
+                  if (j >= 26 && j < 34 && (j & 1) == 0) lw_split(set[PAR], (j - 26) >> 1, real);
+                  if (j == 34) lw_store(o2, 0);
+                  if (j == 36) lw_store(o2, 1);
+                  if (j == 38) gload_half(s + 4, set[PAR], 0);
+                  if (j == 40) gload_half(s + 4, set[PAR], 1);
                 });
       }
     }
