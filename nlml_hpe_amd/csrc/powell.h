@@ -214,6 +214,67 @@ NLML_HD bool linesearch_step(PowellState& s, double fin, double tol) {
   return false;
 }
 
+// The dominant call, as straight-line code: a line search suspended inside Brent's loop (label 10) is resumed with f(u), finishes
+// that iteration and suspends at the next trial point.  The generic machine does the same through ~60 dependent accesses to
+// the state (on the device: LDS round trips of ONE lane, ~6 k cycles a call); here everything the iteration needs is read up
+// front and written back once.  Same operations in the same order as linesearch_step's loop body.  Returns true when the
+// iteration suspended again at label 10 (state committed); false when it would leave the loop (converged, iteration limit) --
+// then NOTHING has been written and the caller runs the generic machine on the untouched state.
+NLML_HD bool brent_resume_fast(PowellState& s, double fin, double tol) {
+  NLML_FP_STRICT
+  const double cg = 0.3819660, mintol = 1.0e-11;
+  double bx = s.bx, bw = s.bw, bv = s.bv, bfx = s.bfx, bfw = s.bfw, bfv = s.bfv, a = s.a, b = s.b;
+  double deltax = s.deltax, rat = s.rat, u = s.u;
+  double pk[PW_N], xk[PW_N];
+  for (int k = 0; k < PW_N; ++k) { pk[k] = s.p[k]; xk[k] = s.xi[k]; }
+  const int it = s.it + 1;
+  const double fu = fin;
+  if (fu > bfx) {
+    if (u < bx) a = u; else b = u;
+    if ((fu <= bfw) || (bw == bx)) {
+      bv = bw; bw = u; bfv = bfw; bfw = fu;
+    } else if ((fu <= bfv) || (bv == bx) || (bv == bw)) {
+      bv = u; bfv = fu;
+    }
+  } else {
+    if (u >= bx) a = bx; else b = bx;
+    bv = bw; bw = bx; bx = u;
+    bfv = bfw; bfw = bfx; bfx = fu;
+  }
+  if (!(it < 500)) return false;
+  const double tol1 = tol * fabs(bx) + mintol;
+  const double tol2 = 2.0 * tol1;
+  const double xmid = 0.5 * (a + b);
+  if (fabs(bx - xmid) < (tol2 - 0.5 * (b - a))) return false;   // converged: the generic machine finishes the search
+  if (fabs(deltax) <= tol1) {
+    deltax = (bx >= xmid) ? a - bx : b - bx;
+    rat = cg * deltax;
+  } else {
+    double tmp1 = (bx - bw) * (bfx - bfv);
+    double tmp2 = (bx - bv) * (bfx - bfw);
+    double pp = (bx - bv) * tmp2 - (bx - bw) * tmp1;
+    tmp2 = 2.0 * (tmp2 - tmp1);
+    if (tmp2 > 0.0) pp = -pp;
+    tmp2 = fabs(tmp2);
+    const double dx_temp = deltax;
+    deltax = rat;
+    if ((pp > tmp2 * (a - bx)) && (pp < tmp2 * (b - bx)) && (fabs(pp) < fabs(0.5 * tmp2 * dx_temp))) {
+      rat = pp * 1.0 / tmp2;
+      u = bx + rat;
+      if ((u - a) < tol2 || (b - u) < tol2) rat = (xmid - bx >= 0) ? tol1 : -tol1;
+    } else {
+      deltax = (bx >= xmid) ? a - bx : b - bx;
+      rat = cg * deltax;
+    }
+  }
+  if (fabs(rat) < tol1) u = (rat >= 0) ? bx + tol1 : bx - tol1;
+  else u = bx + rat;
+  s.bx = bx; s.bw = bw; s.bv = bv; s.bfx = bfx; s.bfw = bfw; s.bfv = bfv; s.a = a; s.b = b;
+  s.deltax = deltax; s.rat = rat; s.u = u; s.fu = fu; s.it = it;
+  for (int k = 0; k < PW_N; ++k) s.xeval[k] = pk[k] + u * xk[k];
+  return true;
+}
+
 // Advance the minimiser.  First call: fin is ignored.  Returns true when the caller must evaluate
 // the objective at s.xeval and call again with the value; false when finished (s.x, s.fval,
 // s.nfev, s.iter, s.status hold the result: scipy's res.x, res.fun, res.nfev, res.nit).
@@ -243,6 +304,13 @@ NLML_HD bool powell_step(PowellState& s, double fin) {
     }                                                                         \
   } while (0)
 
+#ifndef NLML_POWELL_NO_FAST_PATH
+  if (s.ls_pc == 10 && (s.pc == 2 || s.pc == 4) && brent_resume_fast(s, fin, s.xtol * 100)) {
+    if (s.nfev >= s.maxfun) { s.status = PW_MAXFEV; s.pc = -1; return false; }   // as PW_LINESEARCH does after a suspension
+    s.nfev += 1;
+    return true;
+  }
+#endif
   switch (s.pc) {
     case 0:
       for (int k = 0; k < PW_N; ++k) s.xeval[k] = s.x[k];

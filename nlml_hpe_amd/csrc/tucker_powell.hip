@@ -29,7 +29,7 @@ typedef __attribute__((address_space(3))) PowellState LdsPowellState;
 __device__ __attribute__((noinline)) bool powell_step_call(LdsPowellState* s, double f) { return powell_step(*(PowellState*)s, f); }
 
 // at most this many live machines: a few-machine pass instead of the 16-wide one -- 13 us (one machine, vector ALUs) or 15 us
-// (2..4, 4x4x4 matrix instruction) a round against 30 us; BASELINE config 3 end to end: 0.119 s, 16-wide rounds only 0.24 s
+// (2..4, 4x4x4 matrix instruction) a round against 30 us; BASELINE config 3 end to end: 0.118 s, 16-wide rounds only 0.24 s
 #ifndef PW_FEW_N
 #define PW_FEW_N 4
 #endif
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
   }
   __syncthreads();
 #ifdef PW_STAMPS   // timing-only diagnostic: cycles per phase summed over the rounds, written over fval[e0 .. e0+3] at the end
-  unsigned long long ph[4] = {0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime();
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime();
 #define PWS(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tp; tp = t_; } while (0)
 #else
 #define PWS(i) do { } while (0)
@@ -187,13 +187,17 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
 
     PWS(2);
     if (me >= 0 && need[me]) {   // resume the state machines with their objective values
-      const bool nd = powell_step_call((LdsPowellState*)&st[me], tucker_err(sh, me));
+      const double fe = tucker_err(sh, me);
+      PWS(4);
+      const bool nd = powell_step_call((LdsPowellState*)&st[me], fe);
+      PWS(5);
       need[me] = nd ? 1 : 0;
       if (nd) {
         atomicOr(&livew[(round + 1) & 1], 1 << me);
 #pragma unroll
         for (int k = 0; k < PW_N; ++k) par[me][k] = st[me].xeval[k];
       }
+      PWS(6);
     }
     __syncthreads();
     PWS(3);
@@ -206,7 +210,10 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
     for (int k = 0; k < PW_N; ++k) result[n * PW_N + k] = st[tid].x[k];
     if (fval) fval[n] = st[tid].fval;
 #ifdef PW_STAMPS
-    if (fval && tid < 4) fval[n] = (double)ph[tid];
+    for (int i = 0; i < 8; ++i) {   // lane 0 (machine 0) holds all eight sums
+      const unsigned long long v = __shfl(ph[i], 0, 64);
+      if (fval && tid == i) fval[n] = (double)v;
+    }
 #endif
     if (nfev) nfev[n] = st[tid].nfev;
     if (nit) nit[n] = st[tid].iter;

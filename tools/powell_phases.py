@@ -11,10 +11,12 @@ idx = synth.tucker_grid_indices(64, seed=2)
 Xg = torch.from_numpy(synth.tucker_grid_faces(art, idx, 1e-3, seed=2)).to(dev)
 for copies in (1, 3, 16):
     X = Xg[:1].repeat(copies, 1).contiguous()
-    if copies < 4:
-        X = torch.cat([X, Xg[1:5 - copies]])        # pad the workgroup to >= 4 faces so that fval[0..3] exist (the extra faces finish early)
+    if copies < 8:
+        X = torch.cat([X, Xg[1:9 - copies]])        # pad the workgroup to >= 8 faces so that fval[0..7] exist (the extra faces finish early)
     res = ops.tucker_powell(Wm, X, cp)
     torch.cuda.synchronize()
-    ph = res["fun"][:4].cpu().numpy()
+    ph8 = res["fun"][:8].cpu().numpy()
+    ph = ph8[:4]
     nf = int(res["nfev"].max())
-    print(f"{copies:2d} long-lived machines, {nf} rounds: cycles per round: live-mask {ph[0]/nf:7.0f}  coefficients {ph[1]/nf:7.0f}  evaluation {ph[2]/nf:7.0f}  state machines + barrier {ph[3]/nf:7.0f}  total {ph.sum()/nf:7.0f}")
+    print(f"      inside the last phase (lane 0 = machine 0): objective value {ph8[4]/nf:6.0f}  state machine call {ph8[5]/nf:6.0f}  trial point -> LDS {ph8[6]/nf:6.0f}  barrier {ph8[3]/nf:6.0f}")
+    print(f"{copies:2d} long-lived machines, {nf} rounds: cycles per round: live-mask {ph[0]/nf:7.0f}  coefficients {ph[1]/nf:7.0f}  evaluation {ph[2]/nf:7.0f}  state machines + barrier {ph8[3:7].sum()/nf:7.0f}  total {(ph8[:4].sum()+ph8[4:7].sum())/nf:7.0f}")
