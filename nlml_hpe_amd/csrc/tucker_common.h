@@ -83,6 +83,24 @@ struct TuckerShared {
   double red[TNW][EV];
 };
 
+// Sum over the 16 lanes of a DPP row as the balanced tree ((v0+v1)+(v2+v3))+... -- the tree the xor butterfly
+// v[c] += v[c^1], v[c^2], v[c^4], v[c^8] builds in every lane (the C oracle's device order) -- on the vector ALUs' DPP path
+// (row_shr) instead of four ds_bpermute round trips per value.  The total is valid in lane 15 of the row only.
+template <int N>
+__device__ __forceinline__ double dpp_row_shr(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x110 + N, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x110 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_tree_sum(double v) {
+  v = v + dpp_row_shr<1>(v);
+  v = v + dpp_row_shr<2>(v);
+  v = v + dpp_row_shr<4>(v);
+  v = v + dpp_row_shr<8>(v);
+  return v;
+}
+
 // par(e, k): parameter k (w_y, w_p, w_r, u_id[5]) of evaluation e.  cp4: this thread's cosine row
 // (threads < 144 only).  Leaves acc[mb][r] = x_hat of evaluation (lane>>4) + 4r at column
 // 16*(11*wave + mb) + (lane&15).
@@ -105,7 +123,14 @@ __device__ __forceinline__ void tucker_coef(TuckerShared& sh, const ParT& par, c
 
 // Matrix-core phase (after tucker_coef): leaves acc[mb][r] = x_hat of evaluation (lane>>4) + 4r at column
 // tcol0(wave) + tlcol(lane&15, mb).
-__device__ __forceinline__ void tucker_mfma(TuckerShared& sh, const float* __restrict__ Wm, int tid, f64x4 (&acc)[MBW]) {
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+// `hook(qs)` runs with the loads of K step qs (before its matrix instructions): the callers fetch their x rows a few steps
+// before the end, so that those loads' latency hides behind the last steps instead of following the loop.
+template <typename Hook = NoHook>
+__device__ __forceinline__ void tucker_mfma(TuckerShared& sh, const float* __restrict__ Wm, int tid, f64x4 (&acc)[MBW],
+                                            const Hook& hook = Hook()) {
   const int lane = tid & 63, wv = tid >> 6;
   const int kq = lane >> 4, col = lane & 15;
   const float* wbase = Wm + tcol0(wv);                 // the wave's 176-column segment; always inside the row
@@ -121,6 +146,7 @@ __device__ __forceinline__ void tucker_mfma(TuckerShared& sh, const float* __res
   // 34 K steps in groups of TRING: ring slot = step % TRING, static inside the unrolled group
   auto step = [&](int qs, int slot, bool prefetch) {
     if (prefetch) load11(wbase + row_off(qs + TRING - 1 < TQS ? qs + TRING - 1 : TQS - 1), col, wr[(slot + TRING - 1) % TRING]);
+    hook(qs);
     const double a = sh.coef[4 * qs + kq][col];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -233,9 +259,8 @@ __device__ __attribute__((noinline)) void tucker_few(TuckerShared& sh, TuckerFew
         const double dv = few.d[n][wv][tlcol(lane, mb)];
         s = tcol_live(wv, lane, mb) ? fma(dv, dv, s) : s;
       }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
-      if (lane == 0) sh.red[wv][ev[n]] = s;
+      s = row16_tree_sum(s);
+      if (lane == 15) sh.red[wv][ev[n]] = s;
     }
   }
 }
@@ -298,9 +323,8 @@ __device__ __attribute__((noinline)) void tucker_mfma4(TuckerShared& sh, const f
     const double d = (double)xv[mb] - acc[mb];
     s = tcol_live(wv, col, mb) ? fma(d, d, s) : s;
   }
-#pragma unroll
-  for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
-  if (col == 0 && id < ne) sh.red[wv][evd] = s;
+  s = row16_tree_sum(s);
+  if (col == 15 && id < ne) sh.red[wv][evd] = s;
 }
 
 // Residual norms of the 16 evaluations.  xv[mb][r] = x of evaluation (lane>>4) + 4r at this lane's column of
@@ -320,9 +344,8 @@ __device__ __forceinline__ void tucker_residual(TuckerShared& sh, const float (&
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) s[r] += __shfl_xor(s[r], off, 64);
-    if (col == 0) sh.red[wv][(lane >> 4) + 4 * r] = s[r];
+    s[r] = row16_tree_sum(s[r]);
+    if (col == 15) sh.red[wv][(lane >> 4) + 4 * r] = s[r];
   }
   __syncthreads();
 }

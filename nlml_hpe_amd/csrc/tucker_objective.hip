@@ -12,6 +12,10 @@
 
 namespace nlml {
 
+#ifndef K3_XSTEP
+#define K3_XSTEP 3     // the x rows are fetched with the loads of K step 34 - K3_XSTEP
+#endif
+
 struct GlobalPar {
   const double* p;   // params of this block's first evaluation
   int64_t left;      // evaluations available from there (>= 1)
@@ -43,29 +47,39 @@ __global__ __launch_bounds__(TNT, 2) void tucker_objective_kernel(
   K3S(0);
   tucker_coef(sh, par, cp4, tid);
   K3S(1);
-  tucker_mfma(sh, Wm, tid, acc);
-  K3S(2);
-
-  // (fetching the x rows before the matrix-core phase instead was measured: no gain, 57.2 vs 58.1 % at N = 4,096)
+  // this lane's four x rows (evaluations (lane >> 4) + 4r); fetched K3_XSTEP steps before the end of the matrix-core phase
   const int lane = tid & 63, wv = tid >> 6, col = lane & 15;
-  float xv[MBW][4];
+  const float* xrow[4];
+  bool xlive[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int e = (lane >> 4) + 4 * r;
-    const int64_t n = e0 + e;
-    const bool live = n < N;
-    const int64_t nn = live ? n : N - 1;
-    const int64_t xr = x_index ? (int64_t)x_index[nn] : nn;
-    float v[MBW];
-    tucker_load_x(x + xr * ldx, tid, v);
-#pragma unroll
-    for (int mb = 0; mb < MBW; ++mb) {
-      xv[mb][r] = v[mb];
-#ifndef K3_STAMPS
-      if (x_hat && live && tcol_live(wv, col, mb)) x_hat[n * TM + tcol0(wv) + tlcol(col, mb)] = acc[mb][r];
-#endif
-    }
+    const int64_t n = e0 + (lane >> 4) + 4 * r;
+    xlive[r] = n < N;
+    const int64_t nn = xlive[r] ? n : N - 1;
+    xrow[r] = x + (x_index ? (int64_t)x_index[nn] : nn) * ldx;
   }
+  float xv[MBW][4];
+  auto xfetch = [&](int qs) {
+    if (qs != TQS - K3_XSTEP) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v[MBW];
+      tucker_load_x(xrow[r], tid, v);
+#pragma unroll
+      for (int mb = 0; mb < MBW; ++mb) xv[mb][r] = v[mb];
+    }
+  };
+  tucker_mfma(sh, Wm, tid, acc, xfetch);
+  K3S(2);
+#ifndef K3_STAMPS
+  if (x_hat) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int mb = 0; mb < MBW; ++mb)
+        if (xlive[r] && tcol_live(wv, col, mb)) x_hat[(e0 + (lane >> 4) + 4 * r) * TM + tcol0(wv) + tlcol(col, mb)] = acc[mb][r];
+  }
+#endif
   K3S(3);
   tucker_residual(sh, xv, acc, tid);
   K3S(4);

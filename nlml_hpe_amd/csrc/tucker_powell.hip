@@ -29,7 +29,7 @@ typedef __attribute__((address_space(3))) PowellState LdsPowellState;
 __device__ __attribute__((noinline)) bool powell_step_call(LdsPowellState* s, double f) { return powell_step(*(PowellState*)s, f); }
 
 // at most this many live machines: a few-machine pass instead of the 16-wide one -- 13 us (one machine, vector ALUs) or 15 us
-// (2..4, 4x4x4 matrix instruction) a round against 30 us; BASELINE config 3 end to end: 0.118 s, 16-wide rounds only 0.24 s
+// (2..4, 4x4x4 matrix instruction) a round against 30 us; BASELINE config 3 end to end: 0.117 s, 16-wide rounds only 0.24 s
 #ifndef PW_FEW_N
 #define PW_FEW_N 4
 #endif
@@ -43,6 +43,7 @@ __device__ __attribute__((noinline)) void tucker_round16(TuckerShared& sh, const
                                                          int64_t ldx, int64_t e0, int64_t N, int tid) {
   f64x4 acc[MBW];
   tucker_mfma(sh, Wm, tid, acc);
+  // (K3 fetches its x rows with the loads of one of the last K steps; here the 44 extra live registers spill: measured slower)
   float xv[MBW][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
