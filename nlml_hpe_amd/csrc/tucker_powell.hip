@@ -57,9 +57,11 @@ __device__ __attribute__((noinline)) void tucker_round16(TuckerShared& sh, const
   tucker_residual(sh, xv, acc, tid);
 }
 
+// The trial point of machine e IS its state's xeval field: the evaluation passes read the parameters straight from the machines
+// (a separate copy per round cost ~450 cycles of one lane's LDS round trips).
 struct LdsPar {
-  const double (*p)[PW_N];
-  __device__ __forceinline__ double operator()(int e, int k) const { return p[e][k]; }
+  const PowellState* st;
+  __device__ __forceinline__ double operator()(int e, int k) const { return st[e].xeval[k]; }
 };
 
 // ORDER = NLML_TD_ORDER_FAST: the objective as a GEMM on the f64 matrix cores (tucker_common.h); NLML_TD_ORDER_REFERENCE: in the
@@ -72,7 +74,6 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
     int32_t* __restrict__ nfev, int32_t* __restrict__ nit, int32_t* __restrict__ status) {
   __shared__ __attribute__((aligned(16))) TuckerShared sh;
   __shared__ PowellState st[EV];
-  __shared__ double par[EV][PW_N];
   __shared__ int need[EV];
 
   const int tid = threadIdx.x;
@@ -94,14 +95,14 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
 #pragma unroll
     for (int k = 0; k < PW_N; ++k) z[k] = (x0 && live) ? x0[(e0 + me) * PW_N + k] : 0.0;
     powell_init(st[me], z);
+#pragma unroll
+    for (int k = 0; k < PW_N; ++k) st[me].xeval[k] = 0.0;   // slots beyond N are evaluated too (and ignored): defined parameters
     const bool nd = live && powell_step_call((LdsPowellState*)&st[me], 0.0);
     need[me] = nd ? 1 : 0;
-#pragma unroll
-    for (int k = 0; k < PW_N; ++k) par[me][k] = st[me].xeval[k];
   }
   __syncthreads();
 
-  const LdsPar lp{par};
+  const LdsPar lp{st};
   // live machines as one word per round parity: the machines that want another evaluation OR their bit into the next round's
   // word (sixteen LDS reads per thread and round before)
   __shared__ int livew[2];
@@ -132,11 +133,7 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
       if (me >= 0 && need[me]) {
         const bool nd = powell_step_call((LdsPowellState*)&st[me], rs.err[me]);
         need[me] = nd ? 1 : 0;
-        if (nd) {
-          atomicOr(&livew[(round + 1) & 1], 1 << me);
-#pragma unroll
-          for (int k = 0; k < PW_N; ++k) par[me][k] = st[me].xeval[k];
-        }
+        if (nd) atomicOr(&livew[(round + 1) & 1], 1 << me);
       }
       __syncthreads();
     } else {   // NLML_TD_ORDER_FAST (discarded in the other instantiation: its LDS is the reference pass's)
@@ -193,11 +190,7 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
       const bool nd = powell_step_call((LdsPowellState*)&st[me], fe);
       PWS(5);
       need[me] = nd ? 1 : 0;
-      if (nd) {
-        atomicOr(&livew[(round + 1) & 1], 1 << me);
-#pragma unroll
-        for (int k = 0; k < PW_N; ++k) par[me][k] = st[me].xeval[k];
-      }
+      if (nd) atomicOr(&livew[(round + 1) & 1], 1 << me);
       PWS(6);
     }
     __syncthreads();
