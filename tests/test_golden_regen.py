@@ -13,9 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden")
 
 # FX5 (four scipy Powell runs on the reference objective, ~1 min) is left out to keep the CPU suite short
-WHICH = ["1", "2", "2b", "3", "3b", "4", "6", "7", "8", "9"]
+WHICH = ["1", "2", "2b", "3", "3b", "3c", "4", "6", "7", "8", "9"]
 FILES = ["fx1_normalise.npz", "fx2_heads.npz", "fx2b_heads_through_model.npz", "fx3_encoder_heads.npz",
-         "fx3b_reference_range.npz", "fx4_td_objective.npz", "fx6_metrics.json", "fx7_video_in.npz", "fx7_video_math.json",
+         "fx3b_reference_range.npz", "fx3c_reference_range_16k.npz", "fx4_td_objective.npz", "fx6_metrics.json", "fx7_video_in.npz", "fx7_video_math.json",
          "fx8_cosine_table.npz", "fx9_td_gradient.npz"]
 
 
