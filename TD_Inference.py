@@ -23,7 +23,8 @@ def inference(argv=None):
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--order", choices=["reference", "fast"], default="reference",
                     help="objective's operation order: reference = the reference's bits and scipy's own end point (default); "
-                         "fast = f64 matrix cores, end point within 2e-2 deg")
+                         "fast = f64 matrix cores (~3x the faces/s; NOT a parity mode: the end point is sensitive to the last bits of the "
+                         "objective -- 6e-3 deg from scipy on clean grid faces, up to degrees on noisy ones)")
     args = ap.parse_args(argv)
     torch.cuda.set_device(torch.device(args.device))
 

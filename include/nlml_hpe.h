@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NLML_ABI_VERSION 1
+#define NLML_ABI_VERSION 2   /* 2: the TD entry points without _ex default to NLML_TD_ORDER_REFERENCE */
 
 #define NLML_E_BADARG   (-1)  /* null pointer, negative size, misaligned buffer           */
 #define NLML_E_BADBLOB  (-2)  /* packed weight blob has wrong magic / version / F         */
@@ -147,21 +147,24 @@ int nlml_landmarks_to_pose_small(const float* raw, int64_t B, int normalize,
  *   cos_params f64[3,3,4]     optimized_{yaw,pitch,roll}[0:3,:] rows (a,b,c,d) (TD_Inference.py:56)
  *   err        f64[N]
  *   x_hat      f64[N,1404] or NULL
- */
-int nlml_tucker_objective(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,
-                          const double* params, const double* cos_params, int64_t N,
-                          double* err, double* x_hat, void* stream);
-
-/* The same objective with the OPERATION ORDER chosen (nlml_tucker_objective == NLML_TD_ORDER_FAST):
- *   NLML_TD_ORDER_FAST       x_hat = c^T Wm with c = ((u*f_y)*f_p)*f_r as a GEMM on the f64 matrix cores, one fma chain per output;
- *                            agrees with the reference's objective to <= 1e-12 relative (measured ~2e-16);
- *   NLML_TD_ORDER_REFERENCE  np.einsum('ijklm,i,j,k,l->m')'s own loop -- for (i,j,k,l) in nesting order and every m,
- *                            x_hat[m] = ((((W*u_i)*f_yj)*f_pk)*f_rl) + x_hat[m], each operation rounded on its own -- and numpy's
- *                            pairwise np.sum (TD_Tester.py:46,49): err and x_hat are BIT-IDENTICAL to the reference's (FX4);
- *                            vector ALUs, ~5 operations per (q, m) instead of one fma.
+ *
+ * OPERATION ORDER.  The reference's objective is a fixed sequence of separately rounded f64 operations, and the Powell
+ * minimisation on top of it is sensitive to its last bits (the minimum is flat), so the order is part of the contract:
+ *   NLML_TD_ORDER_REFERENCE  (the default of the entry points without _ex: the PARITY mode)
+ *       np.einsum('ijklm,i,j,k,l->m')'s own loop -- for (i,j,k,l) in nesting order and every m,
+ *       x_hat[m] = ((((W*u_i)*f_yj)*f_pk)*f_rl) + x_hat[m], each operation rounded on its own -- and numpy's pairwise np.sum
+ *       (TD_Tester.py:46,49): err and x_hat are BIT-IDENTICAL to the reference's (FX4).  Vector ALUs, 5 operations per (q, m).
+ *       Alignment: Wm and x 4-byte aligned, any ldx >= 1404.
+ *   NLML_TD_ORDER_FAST       (opt-in)
+ *       x_hat = c^T Wm with c = ((u*f_y)*f_p)*f_r as a GEMM on the f64 matrix cores, one fma chain per output; agrees with the
+ *       reference's objective to <= 1e-12 relative (measured ~2e-16), ~5x the evaluations/s.
+ *       Alignment: Wm and x 16-byte aligned and ldx % 4 == 0 (16-byte vector loads), else NLML_E_BADARG.
  */
 #define NLML_TD_ORDER_FAST      0
 #define NLML_TD_ORDER_REFERENCE 1
+int nlml_tucker_objective(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,
+                          const double* params, const double* cos_params, int64_t N,
+                          double* err, double* x_hat, void* stream);          /* == _ex(..., NLML_TD_ORDER_REFERENCE, stream) */
 int nlml_tucker_objective_ex(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,
                              const double* params, const double* cos_params, int64_t N,
                              double* err, double* x_hat, int order, void* stream);
@@ -178,20 +181,19 @@ int nlml_tucker_objective_ex(const float* Wm, const float* x, int64_t ldx, const
  *            np.degrees(result.x)[:3] (:196-199)
  *   fval f64[N], nfev i32[N], nit i32[N], status i32[N] (1 converged, 2 maxfev, 3 maxiter, 4 nan):
  *            scipy's res.fun / res.nfev / res.nit; each may be NULL.
- * The control flow is scipy 1.15.3's (restated in nlml_hpe_amd/csrc/powell.h); because the optimum
- * is flat, last-bit differences in the objective move the final angles by up to ~2e-2 degrees
- * (measured 1.8e-2 on FX5), which is the stated tolerance of this entry point.
+ * The control flow is scipy 1.15.3's (restated in nlml_hpe_amd/csrc/powell.h, checked against scipy step for step on the CPU).
+ *   NLML_TD_ORDER_REFERENCE (default, parity mode): every machine receives the reference's objective values bit for bit, so it
+ *       walks scipy's own trajectory: same evaluation counts, same final angles (FX5: identical bits; 1e-4 deg is the bar).
+ *       (Up to the cos() of the f-vectors: the device's f64 cos and the host libm's may differ in the last place, which can flip the
+ *       f32 rounding of an f-vector entry about once per 1e8 values -- tests/test_gpu_parity.py sweeps 1e6 angles.)
+ *   NLML_TD_ORDER_FAST (opt-in, ~3x the faces/s): the same algorithm on the matrix-core objective.  The minimum is flat and
+ *       Powell's termination is rounding-sensitive, so the END POINT moves under ANY re-ordering of the objective's sums (scipy
+ *       itself: tests/test_powell_sm.py): 6e-3 deg from scipy's on clean grid faces (FX5); on BASELINE config 3's 4,096 noisy
+ *       grid faces median 8.6e-4 deg, 10 % of the faces > 0.02 deg, 0.3 % > 1 deg, max 8.7 deg.  Not a parity mode.
  */
 int nlml_tucker_powell(const float* Wm, const float* x, int64_t ldx, const double* cos_params, int64_t N,
                        const double* x0, double* result, double* fval, int32_t* nfev, int32_t* nit,
-                       int32_t* status, void* stream);
-
-/* The same minimisation over the objective in the chosen operation order (nlml_tucker_powell == NLML_TD_ORDER_FAST).
- * With NLML_TD_ORDER_REFERENCE every machine receives the reference's objective values bit for bit, so it walks scipy's own
- * trajectory: on the reference's FX5 faces the evaluation counts are scipy's and the final angles agree to <= 1e-4 deg
- * (measured: identical bits).  NLML_TD_ORDER_FAST is held to the optimiser tolerance above (2e-2 deg): the minimum is flat and
- * Powell's end point moves by that much under ANY re-ordering of the objective's sums (scipy itself: tests/test_powell_sm.py).
- */
+                       int32_t* status, void* stream);                         /* == _ex(..., NLML_TD_ORDER_REFERENCE, stream) */
 int nlml_tucker_powell_ex(const float* Wm, const float* x, int64_t ldx, const double* cos_params, int64_t N,
                           const double* x0, double* result, double* fval, int32_t* nfev, int32_t* nit,
                           int32_t* status, int order, void* stream);

@@ -60,13 +60,14 @@ def func(w, params):
 
 
 # Operation order of the device objective.  "reference" = np.einsum's own loop order and numpy's pairwise sum: the reference's
-# objective bit for bit, hence scipy's own Powell trajectory and final angles (FX4, FX5) -- the default of the reference-named
-# functions objective() and Test().  "fast" = the GEMM form on the f64 matrix cores (<= 1e-12 relative; Powell's end point within
-# 2e-2 deg) -- the default of the batched forms this build adds.
+# objective bit for bit, hence scipy's own Powell trajectory and final angles (FX4, FX5) -- the DEFAULT of every function here,
+# batched or not: it is the parity mode.  "fast" (opt-in) = the GEMM form on the f64 matrix cores: objective <= 1e-12 relative,
+# ~3x the faces/s, but Powell's end point then differs from scipy's wherever the minimum is flat: 6e-3 deg on FX5's clean grid
+# faces; on BASELINE config 3's 4,096 noisy faces median 8.6e-4 deg, 10 % of the faces > 0.02 deg, 0.3 % > 1 deg, max 8.7 deg.
 ORDER_REFERENCE, ORDER_FAST = "reference", "fast"
 
 
-def objective_batch(params, W, X, params_y, params_p, params_r, x_index=None, return_xhat=False, order=ORDER_FAST):
+def objective_batch(params, W, X, params_y, params_p, params_r, x_index=None, return_xhat=False, order=ORDER_REFERENCE):
     """params f64[N,8]; X f32[M,1404] (M == N, or rows selected by x_index i32[N]) -> err f64[N] (numpy)."""
     P = torch.from_numpy(np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 8)).to(_dev())
     xi = None if x_index is None else torch.from_numpy(np.ascontiguousarray(x_index, dtype=np.int32)).to(_dev())
@@ -127,7 +128,7 @@ def compute_gradient(params, W, x, params_y, params_p, params_r):
 
 
 def Test_batch(W, X, u_id_shape, optimized_params_y, optimized_params_p, optimized_params_r, return_info=False,
-               order=ORDER_FAST):
+               order=ORDER_REFERENCE):
     """Rows of X f32[N,1404] -> degrees f64[N,3] by device-side lock-step Powell (one launch)."""
     if u_id_shape != 5:
         raise ValueError("the device minimiser is built for u_id of size 5 (outputs/features/Factor_Matrices.npz)")

@@ -100,7 +100,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if handle.nlml_abi_version() != 1:
+        if handle.nlml_abi_version() != 2:
             raise NlmlError("libnlml_hpe_hip.so ABI version mismatch")
         _lib = handle
     return _lib

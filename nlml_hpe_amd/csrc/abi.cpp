@@ -114,13 +114,14 @@ int nlml_landmarks_to_pose_small(const float* raw, int64_t B, int normalize, con
                                           ws_bytes, stream);
 }
 
-int nlml_tucker_objective(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,
-                          const double* params, const double* cos_params, int64_t N, double* err, double* x_hat,
-                          void* stream) {
-  if (N < 0) return fail(NLML_E_BADARG, "tucker_objective: negative N");
-  if (N > 0 && (!Wm || !x || !params || !cos_params || !err)) return fail(NLML_E_BADARG, "tucker_objective: null buffer");
-  if (N > 0 && ldx < NLML_F_REFERENCE) return fail(NLML_E_BADARG, "tucker_objective: ldx < 1404");
-  return launch_tucker_objective(Wm, x, ldx, x_index, params, cos_params, N, err, x_hat, NLML_TD_ORDER_FAST, stream);
+// The matrix-core order reads Wm and the x rows with 16-byte vector loads (tucker_common.h load11 / tucker_few)
+static int check_td_fast_alignment(const float* Wm, const float* x, int64_t ldx, const char* who) {
+  if ((reinterpret_cast<uintptr_t>(Wm) & 15) || (reinterpret_cast<uintptr_t>(x) & 15) || (ldx & 3)) {
+    static thread_local char msg[160];
+    snprintf(msg, sizeof msg, "%s: NLML_TD_ORDER_FAST needs Wm and x 16-byte aligned and ldx %% 4 == 0", who);
+    return fail(NLML_E_BADARG, msg);
+  }
+  return 0;
 }
 
 int nlml_tucker_objective_ex(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,
@@ -130,7 +131,15 @@ int nlml_tucker_objective_ex(const float* Wm, const float* x, int64_t ldx, const
   if (N < 0) return fail(NLML_E_BADARG, "tucker_objective: negative N");
   if (N > 0 && (!Wm || !x || !params || !cos_params || !err)) return fail(NLML_E_BADARG, "tucker_objective: null buffer");
   if (N > 0 && ldx < NLML_F_REFERENCE) return fail(NLML_E_BADARG, "tucker_objective: ldx < 1404");
+  if (N > 0 && order == NLML_TD_ORDER_FAST)
+    if (int rc = check_td_fast_alignment(Wm, x, ldx, "tucker_objective")) return rc;
   return launch_tucker_objective(Wm, x, ldx, x_index, params, cos_params, N, err, x_hat, order, stream);
+}
+
+int nlml_tucker_objective(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,
+                          const double* params, const double* cos_params, int64_t N, double* err, double* x_hat,
+                          void* stream) {
+  return nlml_tucker_objective_ex(Wm, x, ldx, x_index, params, cos_params, N, err, x_hat, NLML_TD_ORDER_REFERENCE, stream);
 }
 
 int nlml_video_post(const float* pose_rad, const float* raw, const uint8_t* valid, int64_t S, double frame_w,
@@ -183,15 +192,6 @@ int nlml_powell_result(const void* h_state, double* h_x, double* h_fval, int* h_
   return 0;
 }
 
-int nlml_tucker_powell(const float* Wm, const float* x, int64_t ldx, const double* cos_params, int64_t N,
-                       const double* x0, double* result, double* fval, int32_t* nfev, int32_t* nit,
-                       int32_t* status, void* stream) {
-  if (N < 0) return fail(NLML_E_BADARG, "tucker_powell: negative N");
-  if (N > 0 && (!Wm || !x || !cos_params || !result)) return fail(NLML_E_BADARG, "tucker_powell: null buffer");
-  if (N > 0 && ldx < NLML_F_REFERENCE) return fail(NLML_E_BADARG, "tucker_powell: ldx < 1404");
-  return launch_tucker_powell(Wm, x, ldx, cos_params, N, x0, result, fval, nfev, nit, status, NLML_TD_ORDER_FAST, stream);
-}
-
 int nlml_tucker_powell_ex(const float* Wm, const float* x, int64_t ldx, const double* cos_params, int64_t N,
                           const double* x0, double* result, double* fval, int32_t* nfev, int32_t* nit,
                           int32_t* status, int order, void* stream) {
@@ -199,7 +199,15 @@ int nlml_tucker_powell_ex(const float* Wm, const float* x, int64_t ldx, const do
   if (N < 0) return fail(NLML_E_BADARG, "tucker_powell: negative N");
   if (N > 0 && (!Wm || !x || !cos_params || !result)) return fail(NLML_E_BADARG, "tucker_powell: null buffer");
   if (N > 0 && ldx < NLML_F_REFERENCE) return fail(NLML_E_BADARG, "tucker_powell: ldx < 1404");
+  if (N > 0 && order == NLML_TD_ORDER_FAST)
+    if (int rc = check_td_fast_alignment(Wm, x, ldx, "tucker_powell")) return rc;
   return launch_tucker_powell(Wm, x, ldx, cos_params, N, x0, result, fval, nfev, nit, status, order, stream);
+}
+
+int nlml_tucker_powell(const float* Wm, const float* x, int64_t ldx, const double* cos_params, int64_t N,
+                       const double* x0, double* result, double* fval, int32_t* nfev, int32_t* nit,
+                       int32_t* status, void* stream) {
+  return nlml_tucker_powell_ex(Wm, x, ldx, cos_params, N, x0, result, fval, nfev, nit, status, NLML_TD_ORDER_REFERENCE, stream);
 }
 
 }  // extern "C"

@@ -20,7 +20,7 @@ struct GlobalPar {
   const double* p;   // params of this block's first evaluation
   int64_t left;      // evaluations available from there (>= 1)
   __device__ __forceinline__ double operator()(int e, int k) const {
-    return p[(e < left ? e : left - 1) * 8 + k];
+    return gload<double>(p + (e < left ? e : left - 1) * 8 + k);
   }
 };
 
@@ -87,8 +87,24 @@ __global__ __launch_bounds__(TNT, 2) void tucker_objective_kernel(
   K3S(5);
 }
 
+// row functors of the reference-order pass (passed by value into the non-inlined pass)
+struct ObjXRow {
+  const float* x;
+  const int32_t* x_index;
+  int64_t ldx, e0;
+  __device__ __forceinline__ const float* operator()(int slot) const {
+    const int64_t n = e0 + slot;
+    return x + (x_index ? (int64_t)x_index[n] : n) * ldx;
+  }
+};
+struct ObjXhRow {
+  double* x_hat;
+  int64_t e0;
+  __device__ __forceinline__ double* operator()(int slot) const { return x_hat ? x_hat + (e0 + slot) * TM : (double*)nullptr; }
+};
+
 // NLML_TD_ORDER_REFERENCE: the same 16 evaluations per workgroup in the reference's operation order (tucker_ref.h)
-__global__ __launch_bounds__(TNT, 1) void tucker_objective_ref_kernel(
+__global__ __launch_bounds__(TR_NT, 1) void tucker_objective_ref_kernel(
     const float* __restrict__ Wm, const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ x_index,
     const double* __restrict__ params, const double* __restrict__ cosp, int64_t N, double* __restrict__ err,
     double* __restrict__ x_hat) {
@@ -102,13 +118,21 @@ __global__ __launch_bounds__(TNT, 1) void tucker_objective_ref_kernel(
     cp4[0] = c4[0]; cp4[1] = c4[1]; cp4[2] = c4[2]; cp4[3] = c4[3];
   }
   GlobalPar par{params + e0 * 8, N - e0};
+#ifdef TR_STAMPS   // kernel-level stamps behind the per-pass ones (2 passes x 12 waves x 8 per workgroup): 8 words per workgroup at the end of x_hat
+#define TKS(i) do { if (x_hat && tid == 0) reinterpret_cast<unsigned long long*>(x_hat)[(size_t)gridDim.x * 192 + (size_t)blockIdx.x * 8 + (i)] = (i) >= 4 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TKS(i) do { } while (0)
+#endif
+  TKS(0); TKS(4);
   tucker_fvec(sh, par, cp4, tid);
+  TKS(1);
   const int64_t left = N - e0;
   const int mask = left >= EV ? 0xffff : ((1 << (int)left) - 1);
-  tucker_ref_eval(sh, rs, Wm, par, mask,
-                  [&](int slot) { const int64_t n = e0 + slot; return x + (x_index ? (int64_t)x_index[n] : n) * ldx; },
-                  [&](int slot) { return x_hat ? x_hat + (e0 + slot) * TM : (double*)nullptr; }, tid);
+  tucker_ref_eval(sh, rs, Wm, par, mask, ObjXRow{x, x_index, ldx, e0}, ObjXhRow{x_hat, e0}, tid);
+  TKS(2);
   if (tid < EV && e0 + tid < N) err[e0 + tid] = rs.err[tid];
+  TKS(3); TKS(5);
+#undef TKS
 }
 
 int launch_tucker_objective(const float* Wm, const float* x, int64_t ldx, const int32_t* x_index,
@@ -117,7 +141,7 @@ int launch_tucker_objective(const float* Wm, const float* x, int64_t ldx, const 
   if (N == 0) return 0;
   const dim3 grid((unsigned)((N + EV - 1) / EV)), block(TNT);
   if (order == NLML_TD_ORDER_REFERENCE)
-    hipLaunchKernelGGL(tucker_objective_ref_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), Wm, x, ldx,
+    hipLaunchKernelGGL(tucker_objective_ref_kernel, grid, dim3(TR_NT), 0, reinterpret_cast<hipStream_t>(stream), Wm, x, ldx,
                        x_index, params, cos_params, N, err, x_hat);
   else
   hipLaunchKernelGGL(tucker_objective_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), Wm, x, ldx,

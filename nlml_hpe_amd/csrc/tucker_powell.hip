@@ -61,14 +61,31 @@ __device__ __attribute__((noinline)) void tucker_round16(TuckerShared& sh, const
 // (a separate copy per round cost ~450 cycles of one lane's LDS round trips).
 struct LdsPar {
   const PowellState* st;
-  __device__ __forceinline__ double operator()(int e, int k) const { return st[e].xeval[k]; }
+  __device__ __forceinline__ double operator()(int e, int k) const {
+    return ((const __attribute__((address_space(3))) PowellState*)st)[e].xeval[k];   // a ds_ read, not a flat_ one
+  }
+};
+
+// row functors of the reference-order pass (passed by value into the non-inlined pass)
+struct PowellXRow {
+  const float* x;
+  int64_t ldx, e0, N;
+  __device__ __forceinline__ const float* operator()(int slot) const {
+    int64_t n = e0 + slot;
+    n = n < N ? n : N - 1;
+    return x + n * ldx;
+  }
+};
+struct NoXhRow {
+  static constexpr double* x_hat = nullptr;   // (the stamp build of the pass looks for this member)
+  __device__ __forceinline__ double* operator()(int) const { return nullptr; }
 };
 
 // ORDER = NLML_TD_ORDER_FAST: the objective as a GEMM on the f64 matrix cores (tucker_common.h); NLML_TD_ORDER_REFERENCE: in the
 // reference's own operation order (tucker_ref.h) -- then the machines receive the reference's objective values bit for bit and
 // walk scipy's trajectory (FX5: same evaluation counts, same final angles).
 template <int ORDER>
-__global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void tucker_powell_kernel(
+__global__ __launch_bounds__(ORDER == NLML_TD_ORDER_REFERENCE ? TR_NT : TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void tucker_powell_kernel(
     const float* __restrict__ Wm, const float* __restrict__ x, int64_t ldx, const double* __restrict__ cosp,
     int64_t N, const double* __restrict__ x0, double* __restrict__ result, double* __restrict__ fval,
     int32_t* __restrict__ nfev, int32_t* __restrict__ nit, int32_t* __restrict__ status) {
@@ -88,7 +105,7 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
   // machine e runs on lane e&1 of wave e>>1: two machines per wave, so the divergent state-machine code is at
   // most 2-way serialised and the 8 waves step their machines concurrently (16 machines on the lanes of one
   // wave would serialise up to 16 paths per round)
-  const int me = ((tid & 63) < 2) ? 2 * (tid >> 6) + (tid & 63) : -1;
+  const int me = ((tid & 63) < 2 && tid < 64 * (EV / 2)) ? 2 * (tid >> 6) + (tid & 63) : -1;   // (the reference-order workgroup has 12 waves)
   if (me >= 0) {
     double z[PW_N];
     const bool live = e0 + me < N;
@@ -127,9 +144,7 @@ __global__ __launch_bounds__(TNT, ORDER == NLML_TD_ORDER_REFERENCE ? 1 : 2) void
     if constexpr (ORDER == NLML_TD_ORDER_REFERENCE) {
       __shared__ __attribute__((aligned(16))) TuckerRefShared rs;
       tucker_fvec(sh, lp, cp4, tid);
-      tucker_ref_eval(sh, rs, Wm, lp, live_mask,
-                      [&](int slot) { int64_t n = e0 + slot; n = n < N ? n : N - 1; return x + n * ldx; },
-                      [&](int) { return (double*)nullptr; }, tid);
+      tucker_ref_eval(sh, rs, Wm, lp, live_mask, PowellXRow{x, ldx, e0, N}, NoXhRow{}, tid);
       if (me >= 0 && need[me]) {
         const bool nd = powell_step_call((LdsPowellState*)&st[me], rs.err[me]);
         need[me] = nd ? 1 : 0;
@@ -221,7 +236,7 @@ int launch_tucker_powell(const float* Wm, const float* x, int64_t ldx, const dou
   if (N == 0) return 0;
   const dim3 grid((unsigned)((N + EV - 1) / EV)), block(TNT);
   if (order == NLML_TD_ORDER_REFERENCE)
-    hipLaunchKernelGGL((tucker_powell_kernel<NLML_TD_ORDER_REFERENCE>), grid, block, 0, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL((tucker_powell_kernel<NLML_TD_ORDER_REFERENCE>), grid, dim3(TR_NT), 0, reinterpret_cast<hipStream_t>(stream),
                        Wm, x, ldx, cos_params, N, x0, result, fval, nfev, nit, status);
   else
   hipLaunchKernelGGL((tucker_powell_kernel<NLML_TD_ORDER_FAST>), grid, block, 0, reinterpret_cast<hipStream_t>(stream), Wm, x, ldx,

@@ -1,22 +1,30 @@
-// tucker_ref.h -- the Tucker objective in the REFERENCE'S OWN OPERATION ORDER (NLML_TD_ORDER_REFERENCE).
+// tucker_ref.h -- the Tucker objective in the REFERENCE'S OWN OPERATION ORDER (NLML_TD_ORDER_REFERENCE): the parity mode of the TD path.
 //
-// The fast path (tucker_common.h) evaluates x_hat = c^T Wm as a GEMM on the f64 matrix cores: c = ((u*f_y)*f_p)*f_r first, then one
-// fma chain per output.  That agrees with the reference's objective to ~1e-15 relative -- and still moves the END POINT of the
-// Powell minimisation by up to ~2e-2 degree, because the minimum is flat and Powell's termination is rounding-sensitive
-// (tests/test_powell_sm.py measures scipy itself doing that).  This file evaluates the objective exactly as the reference does
-// (TD_Tester.py:46,49), bit for bit:
+// The matrix-core path (tucker_common.h) evaluates x_hat = c^T Wm as a GEMM: c = ((u*f_y)*f_p)*f_r first, then one fma chain per
+// output.  That agrees with the reference's objective to ~1e-15 relative -- and still moves the END POINT of the Powell
+// minimisation (the minimum is flat and Powell's termination is rounding-sensitive; tests/test_powell_sm.py measures scipy itself
+// doing that).  This file evaluates the objective exactly as the reference does (TD_Tester.py:46,49), bit for bit:
 //
 //   np.einsum('ijklm,i,j,k,l->m', W, u, f_y, f_p, f_r)   numpy's generic sum-of-products loop: for (i,j,k,l) in nesting order,
 //       for every m:  x_hat[m] = ((((W[i,j,k,l,m] * u_i) * f_yj) * f_pk) * f_rl) + x_hat[m],  each operation rounded on its own;
 //   0.5 * np.sum((x - x_hat)**2)                         numpy's pairwise sum: 16 leaves of 80/88/92 elements, each as eight
 //       strided partial sums combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus remainder, the leaves added as a balanced tree.
 //
-// The products cannot be shared between columns (W sits innermost), so this costs 5 f64 operations per (q, m) instead of one
-// fma: ~948 kFLOP-equivalents per evaluation on the vector ALUs, ~25x the matrix-core path's time per evaluation.  It is the
-// parity mode of the TD path (oracle: oracle/csrc/oracle.c oracle_tucker_objective_reforder, pinned to FX4 bit for bit);
-// the matrix-core mode stays the default for throughput.
+// W sits innermost in every product, so nothing can be shared between columns or evaluations: 5 separately rounded f64 operations
+// per (q, m) and evaluation -- 135 * 1404 * 5 = 947,700 vector-ALU operations per evaluation against one fma per (q, m) on the
+// matrix path.  The bound is the f64 vector issue rate (16 lanes per clock and SIMD: 39.3 T operations/s at 2.4 GHz, i.e.
+// 41.5 M evaluations/s); oracle: oracle/csrc/oracle.c oracle_tucker_objective_reforder, pinned to FX4 bit for bit.
 //
-// One workgroup of 512 threads, thread t owns columns t, t+512, t+1024; NE (1, 2, 4 or 8) evaluations share every Wm load.
+// One workgroup of 512 threads; thread t owns columns t, t+512, t+1024 (1404 of the 1536 lane slots are live: 0.914 is the
+// ceiling of any 8-wave column split, 22 wave-columns on 4 SIMDs); NE = 1..8 evaluations share every Wm load.  What keeps the
+// vector ALUs fed (round 3; the round-2 form ran at 0.46 of the issue rate):
+//   * Wm rows come through a three-slot register ring, the loads of block (i,j,k)+2 issued before the arithmetic of block
+//     (i,j,k) (buffer loads: scalar row offset + the lane's column offset, no address arithmetic on the vector ALUs).  Round 2
+//     loaded the nine values of a block at its top and used them at once: 45 exposed L2 round trips per pass;
+//   * the innermost factor f_r[l] of every evaluation lives in scalar registers for the whole pass (it was an LDS read per (l, n)),
+//     u / f_y / f_p are re-read from a compact per-pass LDS table only when their loop level advances;
+//   * every LDS access is a real ds_ instruction (address space 3): through the generic references this non-inlined function
+//     receives they were flat_ loads, which count on vmcnt as well and so waited for the Wm prefetch just issued.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -24,121 +32,263 @@
 
 namespace nlml {
 
-constexpr int TR_COLS = 3;                 // columns per thread: 3 * 512 = 1536 >= 1404
+#ifndef TR_NT_N
+#define TR_NT_N 768
+#endif
+constexpr int TR_NT = TR_NT_N;                // threads of a reference-order workgroup: 12 waves, three per SIMD
+constexpr int TR_COLS = 2;                 // columns per thread: 2 * 768 = 1536 >= 1404
 constexpr int TR_MAXE = 8;                 // evaluations per pass over Wm
 constexpr int TR_LEAVES = 16;              // numpy pairwise tree for n = 1404 (tests/test_oracle_golden.py pins it to np.sum)
+#ifndef TR_ILV_N
+#define TR_ILV_N 4
+#endif
+constexpr int TR_ILV = TR_ILV_N;           // evaluations whose operation chains advance together (x 2 columns)
+constexpr int TR_NFAC = 14;                // u[5], f_y[3], f_p[3], f_r[3] of one evaluation
 
 struct TuckerRefShared {
   double d2[TR_MAXE][TM + 4];              // squared residuals of the pass's evaluations
   double leaf8[TR_MAXE][TR_LEAVES][8];     // strided partial sums of every leaf
   double leaf[TR_MAXE][TR_LEAVES];
+  double fac[TR_MAXE][TR_NFAC + 2];        // the pass's factors, by evaluation
   double err[EV];                          // objective values of the round, by machine slot
 };
 
 __device__ __forceinline__ int tr_leaf_start(int L) { return L == 0 ? 0 : 80 + 88 * (L - 1); }
 __device__ __forceinline__ int tr_leaf_len(int L) { return L == 0 ? 80 : (L == TR_LEAVES - 1 ? 92 : 88); }
 
-// Evaluations ev[0..NE) (machine slots, f-vectors in sh.fvec[slot], parameters par(slot, k)) against the rows xe[i]; results
-// into rs.err[ev[i]] (and x_hat rows if xh[i] != nullptr).  All 512 threads; barriers inside.  `store[i]` false = padding.
-template <int NE, typename ParT>
-__device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh, TuckerRefShared& rs, const float* __restrict__ Wm,
-                                                          const ParT& par, const int (&ev)[NE], const float* const (&xe)[NE],
-                                                          double* const (&xh)[NE], int tid) {
+// LDS accesses through a generic pointer, as ds_ instructions
+template <typename T>
+__device__ __forceinline__ T lds_ld(const void* p) {
+  return *(const __attribute__((address_space(3))) T*)p;
+}
+template <typename T>
+__device__ __forceinline__ void lds_st(void* p, T v) {
+  *(__attribute__((address_space(3))) T*)p = v;
+}
+// a value every lane holds alike, moved to scalar registers
+__device__ __forceinline__ double uniform_f64(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// Evaluations of machine slots (slots >> 4n) & 15, n < NE (f-vectors in sh.fvec[slot], parameters par(slot, k)) against the rows
+// xrow(slot); results into rs.err[slot] (and x_hat rows where xhrow(slot) != nullptr).  All 512 threads; barriers inside.
+// par / xrow / xhrow are small structs passed BY VALUE (a reference into the caller's frame would be scratch memory here).
+template <int NE, typename ParT, typename XRow, typename XhRow>
+__device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh, TuckerRefShared& rs, const float* __restrict__ Wm_,
+                                                          const ParT par, const unsigned slots, const XRow xrow,
+                                                          const XhRow xhrow, const int tid) {
 #pragma clang fp contract(off)
-  int mc[TR_COLS];
+  // LDS through address-space-3 pointers taken ONCE: every access is then a ds_ instruction with an immediate offset from one base
+  // register (per-element casts of generic addresses cost an address register each -- ~30 of the 168 this function may use)
+  typedef __attribute__((address_space(3))) TuckerRefShared LdsRef;
+  typedef __attribute__((address_space(3))) const TuckerShared LdsSh;
+  LdsRef* const rl = (LdsRef*)&rs;
+  LdsSh* const sl = (LdsSh*)&sh;
+#ifdef TR_STAMPS   // timing-only diagnostic build (tools/td_ref_stamps.py): s_memtime at the phase boundaries of each pass into the x_hat buffer
+  unsigned long long* const stamp_base = reinterpret_cast<unsigned long long*>(xhrow.x_hat) +
+                                         (((size_t)blockIdx.x * 2 + ((slots & 15) ? 1 : 0)) * 12 + (tid >> 6)) * 8;
+#define TRS(i) do { if (xhrow.x_hat && (tid & 63) == 0) stamp_base[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TRS(i) do { } while (0)
+#endif
+  TRS(0);
+  // Wm as a buffer resource: a load is (scalar row offset) + (the lane's column offset in a vector register), so the ring costs no
+  // address arithmetic on the vector ALUs, and reads beyond the 135 rows (dead lanes of the last row, the two prefetches past the
+  // last block) return 0 without touching memory.  Arguments of a non-inlined function arrive in vector registers: the base is
+  // made uniform first.
+  const float* Wm = reinterpret_cast<const float*>(
+      ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)Wm_ >> 32)) << 32) |
+      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)Wm_));
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wm, 0, TQ * TM * 4, 0x00027000);
+  unsigned mc[TR_COLS];
   bool livec[TR_COLS];
 #pragma unroll
   for (int c = 0; c < TR_COLS; ++c) {
-    const int m = tid + TNT * c;
-    livec[c] = m < TM;
-    mc[c] = livec[c] ? m : TM - 1;
+    mc[c] = tid + TR_NT * c;
+    livec[c] = mc[c] < (unsigned)TM;
   }
+  // Wm ring: block b = (i*3 + j)*3 + k holds rows 3b .. 3b+2 and lives in slot k; the loads of block b + 2 are issued before the
+  // arithmetic of block b.  (Measured: a five- or nine-slot ring is no faster -- the L2 latency is covered; re-reading u and f_y
+  // from LDS with every block is 7 % slower; holding f_p for all three k in registers spills at the 168 registers that three
+  // waves per SIMD allow.)  f_p is read at the top of its block, u and f_y when their loop level advances.
+  float wr[3][3][TR_COLS];
+  auto wload = [&](int b, float (&dst)[3][TR_COLS]) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int c = 0; c < TR_COLS; ++c)
+        dst[l][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, mc[c] * 4, (3 * b + l) * (TM * 4), 0));
+  };
+  // the pass's factors -> rs.fac[n][0..4] = u, [5..7] = f_y, [8..10] = f_p, [11..13] = f_r.  Their loads are issued first, the
+  // first two blocks of the ring next (memory loads return in order), so the ring's latency overlaps the table and its barrier
+  double facv = 0.0;
+  if (tid < NE * TR_NFAC) {
+    const int n = tid / TR_NFAC, f = tid % TR_NFAC;
+    const int slot = (slots >> (4 * n)) & 15;
+    facv = f < 5 ? par(slot, 3 + f) : sl->fvec[slot][(f - 5) / 3][(f - 5) % 3];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  wload(0, wr[0]);
+  wload(1, wr[1]);
+  __builtin_amdgcn_sched_barrier(0);
+  if (tid < NE * TR_NFAC) rl->fac[tid / TR_NFAC][tid % TR_NFAC] = facv;
+  __syncthreads();
+
+  // the factor table through ONE opaque base register: its LDS address is a compile-time constant beyond the 16-bit offset field,
+  // and hipcc otherwise keeps every element's absolute address in a register of its own across the loop (24 of them)
+  unsigned fac_addr = (unsigned)(uintptr_t)&rl->fac[0][0];
+  asm volatile("" : "+v"(fac_addr));
+  const __attribute__((address_space(3))) double* const fac = (const __attribute__((address_space(3))) double*)(uintptr_t)fac_addr;
+  constexpr int FS = TR_NFAC + 2;          // row stride of rs.fac
+  double fr[3][NE];
+#pragma unroll
+  for (int l = 0; l < 3; ++l)
+#pragma unroll
+    for (int n = 0; n < NE; ++n) fr[l][n] = uniform_f64(fac[n * FS + 11 + l]);
+
   double acc[TR_COLS][NE];
 #pragma unroll
   for (int c = 0; c < TR_COLS; ++c)
 #pragma unroll
     for (int n = 0; n < NE; ++n) acc[c][n] = 0.0;
 
-  // (i, j, k, l) in the einsum's nesting order; the factor of a level is re-read from LDS when that level advances
+#ifdef TR_FP_RESIDENT
+  double fpr[3][NE];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int n = 0; n < NE; ++n) fpr[k][n] = fac[n * FS + 8 + k];
+#endif
+  TRS(1);
+
+  // (i, j, k, l) in the einsum's nesting order
 #pragma unroll 1
   for (int i = 0; i < 5; ++i) {
     double u[NE];
 #pragma unroll
-    for (int n = 0; n < NE; ++n) u[n] = par(ev[n], 3 + i);
+    for (int n = 0; n < NE; ++n) u[n] = fac[n * FS + i];
 #pragma unroll 1
     for (int j = 0; j < 3; ++j) {
       double fy[NE];
 #pragma unroll
-      for (int n = 0; n < NE; ++n) fy[n] = sh.fvec[ev[n]][0][j];
-#pragma unroll 1
+      for (int n = 0; n < NE; ++n) fy[n] = fac[n * FS + 5 + j];
+      const int b0 = (i * 3 + j) * 3;
+#pragma unroll
       for (int k = 0; k < 3; ++k) {
+#ifndef TR_ABL_NOLOAD
+        wload(b0 + k + 2, wr[(k + 2) % 3]);
+#endif
         double fp[NE];
 #pragma unroll
-        for (int n = 0; n < NE; ++n) fp[n] = sh.fvec[ev[n]][1][k];
-        const int q0 = ((i * 3 + j) * 3 + k) * 3;
-        float w[3][TR_COLS];
-#pragma unroll
-        for (int l = 0; l < 3; ++l)
-#pragma unroll
-          for (int c = 0; c < TR_COLS; ++c) w[l][c] = gload<float>(Wm + (size_t)(q0 + l) * TM + mc[c]);
+#ifdef TR_FP_RESIDENT
+        for (int n = 0; n < NE; ++n) fp[n] = fpr[k][n];
+#else
+        for (int n = 0; n < NE; ++n) fp[n] = fac[n * FS + 8 + k];
+#endif
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int l = 0; l < 3; ++l) {
+          double wd[TR_COLS];
 #pragma unroll
-          for (int n = 0; n < NE; ++n) {
-            const double fr = sh.fvec[ev[n]][2][l];
+          for (int c = 0; c < TR_COLS; ++c) wd[c] = (double)wr[k][l][c];
+          // the five operations of a (column, evaluation) pair depend on each other; TR_ILV evaluations x 2 columns advance
+          // together, one operation each per stage (stages pinned by sched_barrier: left alone, hipcc runs the chains one after
+          // the other through a single temporary)
 #pragma unroll
-            for (int c = 0; c < TR_COLS; ++c) {
-              double t = (double)w[l][c] * u[n];
-              t = t * fy[n];
-              t = t * fp[n];
-              t = t * fr;
-              acc[c][n] = t + acc[c][n];
-            }
+          for (int n0 = 0; n0 < NE; n0 += TR_ILV) {
+            double t[TR_ILV][TR_COLS];
+#pragma unroll
+            for (int g = 0; g < TR_ILV; ++g)
+#pragma unroll
+              for (int c = 0; c < TR_COLS; ++c)
+                if (n0 + g < NE) t[g][c] = wd[c] * u[n0 + g];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < TR_ILV; ++g)
+#pragma unroll
+              for (int c = 0; c < TR_COLS; ++c)
+                if (n0 + g < NE) t[g][c] = t[g][c] * fy[n0 + g];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < TR_ILV; ++g)
+#pragma unroll
+              for (int c = 0; c < TR_COLS; ++c)
+                if (n0 + g < NE) t[g][c] = t[g][c] * fp[n0 + g];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < TR_ILV; ++g)
+#pragma unroll
+              for (int c = 0; c < TR_COLS; ++c)
+                if (n0 + g < NE) t[g][c] = t[g][c] * fr[l][n0 + g];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < TR_ILV; ++g)
+#pragma unroll
+              for (int c = 0; c < TR_COLS; ++c)
+                if (n0 + g < NE) acc[c][n0 + g] = t[g][c] + acc[c][n0 + g];
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
     }
   }
+  TRS(2);
   // residuals squared -> LDS (and x_hat out)
 #pragma unroll
-  for (int n = 0; n < NE; ++n)
+  for (int n = 0; n < NE; ++n) {
+    const int slot = (slots >> (4 * n)) & 15;
+    const float* xr = xrow(slot);
+#ifdef TR_STAMPS
+    double* xh = nullptr;
+#else
+    double* xh = xhrow(slot);
+#endif
 #pragma unroll
     for (int c = 0; c < TR_COLS; ++c)
       if (livec[c]) {
-        const double d = (double)gload<float>(xe[n] + mc[c]) - acc[c][n];
-        rs.d2[n][mc[c]] = d * d;
-        if (xh[n]) xh[n][mc[c]] = acc[c][n];
+        const double d = (double)gload<float>(xr + mc[c]) - acc[c][n];
+        rl->d2[n][mc[c]] = d * d;
+        if (xh) xh[mc[c]] = acc[c][n];
       }
+  }
   __syncthreads();
+  TRS(3);
   // numpy's pairwise sum, level 1: eight strided partial sums per leaf
-  for (int t = tid; t < NE * TR_LEAVES * 8; t += TNT) {
+  for (int t = tid; t < NE * TR_LEAVES * 8; t += TR_NT) {
     const int n = t / (TR_LEAVES * 8), L = (t / 8) % TR_LEAVES, jj = t % 8;
-    const double* a = rs.d2[n] + tr_leaf_start(L);
+    const __attribute__((address_space(3))) double* a = rl->d2[n] + tr_leaf_start(L);
     const int len = tr_leaf_len(L), body = len - (len % 8);
     double r = a[jj];
     for (int i2 = 8 + jj; i2 < body; i2 += 8) r += a[i2];
-    rs.leaf8[n][L][jj] = r;
+    rl->leaf8[n][L][jj] = r;
   }
   __syncthreads();
+  TRS(4);
   // level 2: combine the eight, then the remainder elements one by one
-  for (int t = tid; t < NE * TR_LEAVES; t += TNT) {
+  for (int t = tid; t < NE * TR_LEAVES; t += TR_NT) {
     const int n = t / TR_LEAVES, L = t % TR_LEAVES;
-    const double* r = rs.leaf8[n][L];
+    const __attribute__((address_space(3))) double* r = rl->leaf8[n][L];
     double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    const double* a = rs.d2[n] + tr_leaf_start(L);
+    const __attribute__((address_space(3))) double* a = rl->d2[n] + tr_leaf_start(L);
     const int len = tr_leaf_len(L);
     for (int i2 = len - (len % 8); i2 < len; ++i2) res += a[i2];
-    rs.leaf[n][L] = res;
+    rl->leaf[n][L] = res;
   }
   __syncthreads();
+  TRS(5);
   // level 3: the balanced tree over the 16 leaves, then * 0.5
   if (tid < NE) {
-    const double* s = rs.leaf[tid];
+    double s[TR_LEAVES];
+#pragma unroll
+    for (int L = 0; L < TR_LEAVES; ++L) s[L] = rl->leaf[tid][L];
     const double a0 = (s[0] + s[1]) + (s[2] + s[3]), a1 = (s[4] + s[5]) + (s[6] + s[7]);
     const double a2 = (s[8] + s[9]) + (s[10] + s[11]), a3 = (s[12] + s[13]) + (s[14] + s[15]);
-    rs.err[ev[tid]] = 0.5 * ((a0 + a1) + (a2 + a3));
+    rl->err[(slots >> (4 * tid)) & 15] = 0.5 * ((a0 + a1) + (a2 + a3));
   }
   __syncthreads();
+  TRS(6);
+#undef TRS
 }
 
 // f-vectors of all 16 slots into sh.fvec (tucker_coef's first half; the coefficient table is not used in this order)
@@ -152,33 +302,32 @@ __device__ __forceinline__ void tucker_fvec(TuckerShared& sh, const ParT& par, c
   __syncthreads();
 }
 
-// The evaluations whose bit is set in `mask` (machine slots), in passes of 8 / 4 / 2 / 1.  xrow(slot) -> that slot's x row;
-// xhrow(slot) -> its x_hat output row or nullptr.
+// The evaluations whose bit is set in `mask` (machine slots), up to eight per pass over Wm.  A pass costs what its evaluations
+// cost on the vector ALUs (~6 us each at the issue rate) but never less than streaming Wm through the CU (~10 us), so nine or
+// more live machines go as two passes of about the same size.  xrow(slot) -> that slot's x row; xhrow(slot) -> its x_hat output
+// row or nullptr.
 template <typename ParT, typename XRow, typename XhRow>
 __device__ __forceinline__ void tucker_ref_eval(const TuckerShared& sh, TuckerRefShared& rs, const float* __restrict__ Wm,
-                                                const ParT& par, int mask, XRow xrow, XhRow xhrow, int tid) {
+                                                const ParT par, int mask, const XRow xrow, const XhRow xhrow, int tid) {
   while (mask) {
     const int cnt = __popc(mask);
-    int slots[TR_MAXE];
-    int take = cnt >= 8 ? 8 : (cnt >= 4 ? 4 : (cnt >= 2 ? 2 : 1));
+    const int take = cnt <= TR_MAXE ? cnt : (cnt + 1) / 2;   // cnt <= EV = 16
+    unsigned slots = 0;
     for (int i = 0; i < take; ++i) {
-      slots[i] = __ffs(mask) - 1;
+      slots |= (unsigned)(__ffs(mask) - 1) << (4 * i);
       mask &= mask - 1;
     }
-#define NLML_REF_CASE(K)                                                                   \
-  case K: {                                                                                \
-    int ek[K];                                                                             \
-    const float* xk[K];                                                                    \
-    double* hk[K];                                                                         \
-    for (int i = 0; i < K; ++i) { ek[i] = slots[i]; xk[i] = xrow(slots[i]); hk[i] = xhrow(slots[i]); } \
-    tucker_ref_pass<K>(sh, rs, Wm, par, ek, xk, hk, tid);                                  \
-    break;                                                                                 \
-  }
     switch (take) {
-      NLML_REF_CASE(8) NLML_REF_CASE(4) NLML_REF_CASE(2) NLML_REF_CASE(1)
+      case 8: tucker_ref_pass<8>(sh, rs, Wm, par, slots, xrow, xhrow, tid); break;
+      case 7: tucker_ref_pass<7>(sh, rs, Wm, par, slots, xrow, xhrow, tid); break;
+      case 6: tucker_ref_pass<6>(sh, rs, Wm, par, slots, xrow, xhrow, tid); break;
+      case 5: tucker_ref_pass<5>(sh, rs, Wm, par, slots, xrow, xhrow, tid); break;
+      case 4: tucker_ref_pass<4>(sh, rs, Wm, par, slots, xrow, xhrow, tid); break;
+      case 3: tucker_ref_pass<3>(sh, rs, Wm, par, slots, xrow, xhrow, tid); break;
+      case 2: tucker_ref_pass<2>(sh, rs, Wm, par, slots, xrow, xhrow, tid); break;
+      case 1: tucker_ref_pass<1>(sh, rs, Wm, par, slots, xrow, xhrow, tid); break;
       default: break;
     }
-#undef NLML_REF_CASE
   }
 }
 

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(repo_root):
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/nlml_hpe.h but not exported"
     assert set(names) == set(_lib.SYMBOLS), "ctypes table and header disagree"
-    assert _lib.lib().nlml_abi_version() == 1
+    assert _lib.lib().nlml_abi_version() == 2
 
 
 @pytest.mark.parametrize("F", [1404, 136, 13])

@@ -133,7 +133,7 @@ def test_fx4_tucker_objective_golden(tucker_art, golden_dir, device):
     g = np.load(os.path.join(golden_dir, "fx4_td_objective.npz"))
     Wm = torch.from_numpy(tucker_art["W"].reshape(135, 1404)).to(device)
     err, xh = ops.tucker_objective(Wm, torch.from_numpy(g["x"]).to(device), torch.from_numpy(g["params"]).to(device),
-                                   torch.from_numpy(_cos_params(tucker_art)).to(device), return_xhat=True)
+                                   torch.from_numpy(_cos_params(tucker_art)).to(device), return_xhat=True, order="fast")
     err = err.cpu().numpy()
     assert np.max(np.abs(err - g["err"]) / np.abs(g["err"])) <= 1e-12
     xh = xh.cpu().numpy()[:8]
@@ -149,7 +149,7 @@ def test_tucker_objective_shared_rows_and_ragged(tucker_art, device):
     ref = TK.objective_batch(P, tucker_art["W"], X[idx], cp[0], cp[1], cp[2])
     Wm = torch.from_numpy(tucker_art["W"].reshape(135, 1404)).to(device)
     err = ops.tucker_objective(Wm, torch.from_numpy(X).to(device), torch.from_numpy(P).to(device),
-                               torch.from_numpy(cp).to(device), x_index=torch.from_numpy(idx).to(device))
+                               torch.from_numpy(cp).to(device), x_index=torch.from_numpy(idx).to(device), order="fast")
     assert np.max(np.abs(err.cpu().numpy() - ref) / np.abs(ref)) <= 1e-12
 
 
@@ -187,7 +187,8 @@ def test_mfma_chain_bitexact_vs_c_oracle(F, B, gain, head_sds, device):
     assert np.degrees(np.abs(out.cpu().numpy() - c_out).max()) <= POSE_TOL_DEG
 
 
-TD_FAST_TOL_DEG = 2e-2      # fast (matrix-core) TD mode: Powell's end point under a re-ordered objective, tests/test_powell_sm.py
+TD_FAST_TOL_DEG = 2e-2      # fast (matrix-core) TD mode ON FX5's CLEAN GRID FACES ONLY (not a parity mode: on noisy faces its end point
+                            # can be degrees away, bench.py extra.td_powell_fast_order); tests/test_powell_sm.py
 TD_REF_TOL_DEG = 1e-4       # reference-order TD mode: the bar of north_star (measured: identical bits)
 
 
@@ -205,7 +206,7 @@ def test_fx5_powell_on_device(tucker_art, golden_dir, device):
     assert (info["status"] == 1).all()
     assert d <= TD_FAST_TOL_DEG, (deg, g["deg"])
     # the objective at the device's minimiser is as low as at scipy's (both ~0 for grid faces)
-    f_dev = TD.objective_batch(info["x"], tucker_art["W"], g["x"], Py, Pp, Pr)
+    f_dev = TD.objective_batch(info["x"], tucker_art["W"], g["x"], Py, Pp, Pr, order="fast")
     assert np.allclose(f_dev, info["fun"], rtol=1e-9, atol=1e-15)
     y, p, r, uid = TD.Test(tucker_art["W"], torch.from_numpy(g["x"][1]), 5, Py, Pp, Pr, None, None, None, None, order="fast")
     assert uid is None and abs(y - g["deg"][1][0]) <= TD_FAST_TOL_DEG
@@ -223,7 +224,7 @@ def test_fx4_objective_reference_order_is_bit_exact(tucker_art, golden_dir, devi
                                    return_xhat=True, order="reference")
     assert np.array_equal(err.cpu().numpy(), g["err"])
     assert np.array_equal(xh.cpu().numpy()[:8], g["x_hat"])
-    for N in (1, 7, 16, 45):                                   # partial passes of 1 / 2 / 4 / 8 evaluations, several workgroups
+    for N in (1, 2, 3, 5, 6, 7, 9, 11, 13, 16, 45):            # passes of every size 1..8 (9..16 go as two), several workgroups
         P = synth.tucker_params(N, 5, seed=30 + N)
         X = synth.features(5, 1404, seed=31)
         idx = (np.arange(N) * 3 % 5).astype(np.int32)
@@ -265,8 +266,8 @@ def test_powell_batch_ragged_and_independent(tucker_art, device):
     idx = synth.tucker_grid_indices(13, seed=8)
     X = np.stack([TK.grid_reconstruction(fm["W"], fm["U_id"][i], fm["U_yaw"][j], fm["U_pitch"][k], fm["U_roll"][l])
                   for i, j, k, l in idx])
-    deg, info = TD.Test_batch(fm["W"], X, 5, Py, Pp, Pr, return_info=True)
-    solo, info1 = TD.Test_batch(fm["W"], X[9:10], 5, Py, Pp, Pr, return_info=True)
+    deg, info = TD.Test_batch(fm["W"], X, 5, Py, Pp, Pr, return_info=True, order="fast")
+    solo, info1 = TD.Test_batch(fm["W"], X[9:10], 5, Py, Pp, Pr, return_info=True, order="fast")
     assert np.array_equal(deg[9], solo[0]) and info["nfev"][9] == info1["nfev"][0]
     # reported only: how far the TD method lands from the grid pose (a property of the reference's model --
     # extreme bins fall into other local minima -- not of this implementation)
@@ -287,10 +288,10 @@ def test_device_powell_replays_exactly_on_the_cpu(tucker_art, golden_dir, device
     Py, Pp, Pr = tucker_art["optimized_yaw"][:3], tucker_art["optimized_pitch"][:3], tucker_art["optimized_roll"][:3]
     cp = np.stack([Py, Pp, Pr])
     X = g["x"][:2]
-    deg, info = TD.Test_batch(W, X, 5, Py, Pp, Pr, return_info=True)
+    deg, info = TD.Test_batch(W, X, 5, Py, Pp, Pr, return_info=True, order="fast")
     # objective level first: device == C oracle in device order, bitwise
     P = synth.tucker_params(64, 5, seed=12)
-    e_dev = TD.objective_batch(P, W, np.repeat(X[:1], 64, axis=0), Py, Pp, Pr)
+    e_dev = TD.objective_batch(P, W, np.repeat(X[:1], 64, axis=0), Py, Pp, Pr, order="fast")
     e_c = CO.tucker_objective(W, np.repeat(X[:1], 64, axis=0), P, cp, device_order=True)
     assert np.array_equal(e_dev, e_c)
     for i in range(2):

@@ -13,7 +13,7 @@ for copies in (1, 3, 16):
     X = Xg[:1].repeat(copies, 1).contiguous()
     if copies < 8:
         X = torch.cat([X, Xg[1:9 - copies]])        # pad the workgroup to >= 8 faces so that fval[0..7] exist (the extra faces finish early)
-    res = ops.tucker_powell(Wm, X, cp)
+    res = ops.tucker_powell(Wm, X, cp, order="fast")
     torch.cuda.synchronize()
     ph8 = res["fun"][:8].cpu().numpy()
     ph = ph8[:4]

@@ -10,7 +10,7 @@ Wm = torch.from_numpy(art["W"].reshape(135, 1404)).to(dev)
 cp = torch.from_numpy(np.stack([art["optimized_yaw"][:3], art["optimized_pitch"][:3], art["optimized_roll"][:3]])).to(dev)
 idx = synth.tucker_grid_indices(64, seed=2)
 Xg = torch.from_numpy(synth.tucker_grid_faces(art, idx, 1e-3, seed=2)).to(dev)
-for copies in (1, 2, 3, 4, 5, 8, 16):
+for copies in (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16):
     X = Xg[:1].repeat(copies, 1).contiguous()
     ops.tucker_powell(Wm, X, cp, order=order); torch.cuda.synchronize()
     t0 = time.perf_counter()
