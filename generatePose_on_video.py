@@ -64,11 +64,14 @@ def process_video(source, output_path, model, save_output, device="cuda:0", worl
     if clips.ndim != 4 or clips.shape[2:] != (468, 3):
         raise ValueError(f"landmarks must be [T,S,468,3], got {clips.shape}")
     T, S_all = clips.shape[:2]
+    # decided from (S_all, world) alone, so EVERY rank takes the same exit before any collective: a rank that left alone here would
+    # leave the others blocked in the collation's all-gather
+    empty = [r for r in range(world) if shard_bounds(S_all, world, r)[0] >= shard_bounds(S_all, world, r)[1]]
+    if empty:
+        raise SystemExit(f"{S_all} streams over {world} ranks leaves ranks {empty} without a stream: use at most {S_all} ranks")
     s0, s1, per = shard_bounds(S_all, world, rank)            # this rank's contiguous block of streams
     clips = clips[:, s0:s1]
     S = s1 - s0
-    if S == 0:
-        raise SystemExit(f"rank {rank}: no stream left for it ({S_all} streams over {world} ranks)")
     tracker = VideoPoseTracker(model, S, width, height)
     frames = torch.from_numpy(np.ascontiguousarray(clips)).to(device)
     lat = []

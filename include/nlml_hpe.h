@@ -68,15 +68,25 @@ int nlml_normalize_ipd(const float* raw, int64_t B, int normalize,
  *   head_w[g][i]/head_b[g][i], g<3 (yaw,pitch,roll), i<5 : model.{0,2,4,6,8}.{weight,bias},
  *                            shapes (128,3) (256,128) (128,256) (64,128) (1,64)
  * (the state-dict layout of models/Encoder.pth and models/{yaw,pitch,roll}_network.pth).
- * mode: NLML_MODE_F32 = f32 storage + f32 MFMA (parity mode, <=1e-4 deg of the reference);
+ * mode: NLML_MODE_F32 = f32 storage + f32 MFMA, layers 0 and 1 summed in blocks of 128 k (the strict parity mode: at the
+ *       reference's operating range -- poses to +-60 deg, FX3c, 16,384 faces -- its distance from the exact result is
+ *       1.5e-5 / 4.9e-5 / 8.5e-5 deg in p50 / p99 / max, no worse than the reference's own 1.7e-5 / 5.5e-5 / 9.9e-5);
  *       NLML_MODE_BF16 = bf16 weights and activations + bf16 MFMA, f32 accumulate (throughput mode:
  *       ~5x the faces/s; its error is ~0.1 deg max / 0.02 deg mean and is never claimed as parity);
  *       NLML_MODE_F16X2 = split-f16 parity mode: every f32 weight and activation is carried as two f16
  *       pieces (hi + lo, 22 significand bits) and a product runs as three f16 MFMAs with f32 accumulation.
- *       Same <=1e-4 deg bar as NLML_MODE_F32 (measured ~1e-5 deg), ~2.6x its faces/s.  No input-range limit: a
+ *       ~1e-5 deg from the reference on small poses; at the reference's operating range (FX3c) 2.1e-5 / 6.7e-5 / 1.26e-4 deg
+ *       from the exact result in p50 / p99 / max = 1.23-1.27x the reference's own distance, 0.05 % of the faces beyond 1e-4
+ *       deg; ~3x NLML_MODE_F32's faces/s (the bench default).  No input-range limit: a
  *       face whose activations leave f16's range (|v| >= 65520 -- e.g. the reference's ipd == 0 -> 1e-6 branch,
  *       FeatureExtractor.py:47-48) is re-evaluated inside the same launch in f32 on the vector ALUs from the same
  *       blob (csrc/encoder_heads_f16x2_rescue.h); NaN/Inf inputs give a non-finite pose, as in the reference.
+ *       COST OF THAT SLOW PATH: rescued faces go four at a time, each group streaming the whole 9.6 MB blob through its CU
+ *       (~0.15 ms).  A handful of such faces per launch is free; a batch in which EVERY face overflows (un-normalised
+ *       pixel-scale landmarks against trained-scale weights) runs ~40x slower: 6.1 ms instead of 0.16 ms for 4,096 faces
+ *       (0.67 M faces/s; tests/test_gpu_parity.py::test_split_f16_every_face_of_a_tile_overflows).  Feed such data to
+ *       NLML_MODE_F32, which has no range limit and no cliff.  Rescued faces use the blob's weights as hi + lo, i.e. 22
+ *       significand bits, not the original f32 weights: ~2x torch-f32's distance from the exact result on such inputs.
  * The forward entry points recognise the mode of a blob by its size.
  */
 #define NLML_MODE_F32   0
@@ -216,6 +226,12 @@ int nlml_tucker_powell_ex(const float* Wm, const float* x, int64_t ldx, const do
 int nlml_video_post(const float* pose_rad, const float* raw, const uint8_t* valid, int64_t S,
                     double frame_w, double frame_h, double alpha, double max_jump, double size,
                     double* state, double* smoothed, double* centre, double* endpoints, void* stream);
+/* The same with   updated  u8[S] or NULL: 1 where this tick was applied to the stream, 0 where it was skipped (no face, or a
+ * non-finite pose) and state / smoothed / centre / endpoints still hold the previous tick's values -- what a caller that saves the
+ * outputs must record as "no new result" (the reference drops such a frame, generatePose_on_video.py:193-196). */
+int nlml_video_post_ex(const float* pose_rad, const float* raw, const uint8_t* valid, int64_t S,
+                       double frame_w, double frame_h, double alpha, double max_jump, double size,
+                       double* state, double* smoothed, double* centre, double* endpoints, uint8_t* updated, void* stream);
 
 /* Artefact producers that are pure tensor algebra.
  *

@@ -142,14 +142,21 @@ int nlml_tucker_objective(const float* Wm, const float* x, int64_t ldx, const in
   return nlml_tucker_objective_ex(Wm, x, ldx, x_index, params, cos_params, N, err, x_hat, NLML_TD_ORDER_REFERENCE, stream);
 }
 
-int nlml_video_post(const float* pose_rad, const float* raw, const uint8_t* valid, int64_t S, double frame_w,
-                    double frame_h, double alpha, double max_jump, double size, double* state, double* smoothed,
-                    double* centre, double* endpoints, void* stream) {
+int nlml_video_post_ex(const float* pose_rad, const float* raw, const uint8_t* valid, int64_t S, double frame_w,
+                       double frame_h, double alpha, double max_jump, double size, double* state, double* smoothed,
+                       double* centre, double* endpoints, uint8_t* updated, void* stream) {
   if (S < 0) return fail(NLML_E_BADARG, "video_post: negative S");
   if (S > 0 && (!pose_rad || !raw || !state || !smoothed || !centre || !endpoints))
     return fail(NLML_E_BADARG, "video_post: null buffer");
   return launch_video_post(pose_rad, raw, valid, S, frame_w, frame_h, alpha, max_jump, size, state, smoothed, centre,
-                           endpoints, stream);
+                           endpoints, updated, stream);
+}
+
+int nlml_video_post(const float* pose_rad, const float* raw, const uint8_t* valid, int64_t S, double frame_w,
+                    double frame_h, double alpha, double max_jump, double size, double* state, double* smoothed,
+                    double* centre, double* endpoints, void* stream) {
+  return nlml_video_post_ex(pose_rad, raw, valid, S, frame_w, frame_h, alpha, max_jump, size, state, smoothed, centre, endpoints,
+                            nullptr, stream);
 }
 
 int nlml_cosine_table(const float* angles_rad, int64_t n, const double* cos_params, int R, double* out, void* stream) {

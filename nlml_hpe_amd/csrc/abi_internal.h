@@ -50,6 +50,6 @@ int launch_tucker_powell(const float* Wm, const float* x, int64_t ldx, const dou
 // video_post.hip
 int launch_video_post(const float* pose_rad, const float* raw, const uint8_t* valid, int64_t S, double frame_w,
                       double frame_h, double alpha, double max_jump, double size, double* state, double* smoothed,
-                      double* centre, double* endpoints, void* stream);
+                      double* centre, double* endpoints, uint8_t* updated, void* stream);
 
 }  // namespace nlml

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "abi_internal.h"
+#include "cr_cos.h"
 
 namespace nlml {
 
@@ -23,7 +24,7 @@ __global__ __launch_bounds__(256) void cosine_table_kernel(const float* __restri
   const double* q = p + 4 * j;
   // numpy evaluates b*w, + c, cos, a*, + d as separately rounded f64 operations: no fma contraction here
   const double arg = __dadd_rn(__dmul_rn(q[1], (double)w[row]), q[2]);
-  out[i] = __dadd_rn(__dmul_rn(q[0], cos(arg)), q[3]);
+  out[i] = __dadd_rn(__dmul_rn(q[0], cr_cos(arg)), q[3]);   // correctly rounded cos (cr_cos.h): the value numpy's libm returns in all but ~1e-3 of the cases, and then 1 ulp away
 }
 
 // 16 x 16 outputs per workgroup, the K range staged through LDS in slices of 64 (both operands are K-contiguous)

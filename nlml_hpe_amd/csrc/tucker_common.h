@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/nlml_hpe.h"
+#include "cr_cos.h"
 
 namespace nlml {
 
@@ -107,9 +108,10 @@ __device__ __forceinline__ double row16_tree_sum(double v) {
 // Coefficient phase: f-vectors and c[q][e] of all 16 evaluations into LDS (two barriers inside).
 template <typename ParT>
 __device__ __forceinline__ void tucker_coef(TuckerShared& sh, const ParT& par, const double (&cp4)[4], int tid) {
+#pragma clang fp contract(off)   // numpy rounds b*w, + c, a*cos, + d separately (TD_Tester.py:25-28); the coefficient products too
   if (tid < EV * 9) {
     const int e = tid / 9, a = (tid % 9) / 3;
-    const double v = cp4[0] * cos(cp4[1] * par(e, a) + cp4[2]) + cp4[3];
+    const double v = cp4[0] * cr_cos(cp4[1] * par(e, a) + cp4[2]) + cp4[3];   // correctly rounded cos: cr_cos.h
     sh.fvec[e][a][tid % 3] = (double)(float)v;                     // .astype(np.float32), :37,40,43
   }
   __syncthreads();

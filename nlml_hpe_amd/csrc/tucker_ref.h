@@ -294,9 +294,10 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
 // f-vectors of all 16 slots into sh.fvec (tucker_coef's first half; the coefficient table is not used in this order)
 template <typename ParT>
 __device__ __forceinline__ void tucker_fvec(TuckerShared& sh, const ParT& par, const double (&cp4)[4], int tid) {
+#pragma clang fp contract(off)   // numpy rounds b*w, + c, a*cos, + d separately (TD_Tester.py:25-28)
   if (tid < EV * 9) {
     const int e = tid / 9, a = (tid % 9) / 3;
-    const double v = cp4[0] * cos(cp4[1] * par(e, a) + cp4[2]) + cp4[3];
+    const double v = cp4[0] * cr_cos(cp4[1] * par(e, a) + cp4[2]) + cp4[3];   // correctly rounded cos: cr_cos.h
     sh.fvec[e][a][tid % 3] = (double)(float)v;
   }
   __syncthreads();

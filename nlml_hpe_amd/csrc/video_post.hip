@@ -9,7 +9,8 @@
 // with the state (smoothed angles, previous centre, prediction count) kept on the device between
 // frames, so a tick of S streams is one launch and no per-face D2H sync.  A stream whose frame has
 // no face (valid == 0) is skipped exactly like the reference's `continue` (:193-196): its state
-// does not change and its outputs are left untouched; so is a stream whose pose is not finite.
+// does not change and its outputs are left untouched; so is a stream whose pose is not finite.  `updated` (optional) tells the
+// caller which streams' ticks were applied, so a skipped stream is never reported with stale outputs as if they were new.
 //
 // One thread per stream, all f64 (the reference computes in Python floats).  round(x, 2) is
 // rint(x*100)/100 (half-to-even), which equals Python's correctly-rounded round() except when
@@ -25,9 +26,10 @@ __global__ void video_post_kernel(const float* __restrict__ pose_rad, const floa
                                   const uint8_t* __restrict__ valid, int64_t S, double frame_w, double frame_h,
                                   double alpha, double max_jump, double size, double* __restrict__ state,
                                   double* __restrict__ smoothed, double* __restrict__ centre,
-                                  double* __restrict__ endpoints) {
+                                  double* __restrict__ endpoints, uint8_t* __restrict__ updated) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
+  if (updated) updated[s] = 0;              // set to 1 below only if this stream's tick is applied
   if (valid && !valid[s]) return;
   // A non-finite pose (NaN/Inf landmarks in) is treated like "no face": the stream's state is left alone.  The reference
   // has no such frame to copy -- its int(x1) at generatePose_on_video.py:121 raises on NaN and ends the loop -- and letting
@@ -54,6 +56,7 @@ __global__ void video_post_kernel(const float* __restrict__ pose_rad, const floa
     if (sqrt(dx * dx + dy * dy) > max_jump) { tdx = st[3]; tdy = st[4]; }         // :99-107
   }
   st[3] = tdx; st[4] = tdy; st[5] += 1.0;
+  if (updated) updated[s] = 1;
   centre[s * 2 + 0] = tdx; centre[s * 2 + 1] = tdy;
   const double kRad = 3.141592653589793 / 180.0;
   const double pitch = ang[1] * kRad, yaw = -(ang[0] * kRad), roll = ang[2] * kRad;   // :74-76
@@ -68,11 +71,11 @@ __global__ void video_post_kernel(const float* __restrict__ pose_rad, const floa
 
 int launch_video_post(const float* pose_rad, const float* raw, const uint8_t* valid, int64_t S, double frame_w,
                       double frame_h, double alpha, double max_jump, double size, double* state, double* smoothed,
-                      double* centre, double* endpoints, void* stream) {
+                      double* centre, double* endpoints, uint8_t* updated, void* stream) {
   if (S == 0) return 0;
   const dim3 grid((unsigned)((S + 63) / 64)), block(64);
   hipLaunchKernelGGL(video_post_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), pose_rad, raw, valid, S,
-                     frame_w, frame_h, alpha, max_jump, size, state, smoothed, centre, endpoints);
+                     frame_w, frame_h, alpha, max_jump, size, state, smoothed, centre, endpoints, updated);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
 }

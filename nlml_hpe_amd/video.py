@@ -26,6 +26,7 @@ class VideoPoseTracker:
         self.smoothed = torch.zeros((self.S, 3), dtype=torch.float64, device=dev)
         self.centre = torch.zeros((self.S, 2), dtype=torch.float64, device=dev)
         self.endpoints = torch.zeros((self.S, 3, 2), dtype=torch.float64, device=dev)
+        self.updated = torch.zeros((self.S,), dtype=torch.uint8, device=dev)   # 1 = the last tick was applied to the stream
 
     def post(self, pose_rad: torch.Tensor, raw: torch.Tensor, valid: torch.Tensor | None = None):
         """One tick given the model outputs: updates state; returns (smoothed deg, centre, endpoints) views."""
@@ -40,18 +41,20 @@ class VideoPoseTracker:
             v8 = valid.to(torch.uint8).contiguous()
         pose_rad, raw = pose_rad.contiguous(), raw.contiguous()
         with ops._on_device_of(("state", self.state), ("pose_rad", pose_rad), ("raw", raw), ("valid", v8)) as stream:
-            _lib.check(_lib.lib().nlml_video_post(
+            _lib.check(_lib.lib().nlml_video_post_ex(
                 pose_rad.data_ptr(), raw.data_ptr(), v8.data_ptr() if v8 is not None else None,
                 self.S, self.frame_w, self.frame_h, self.alpha, self.max_jump, self.size, self.state.data_ptr(),
-                self.smoothed.data_ptr(), self.centre.data_ptr(), self.endpoints.data_ptr(), stream),
-                "nlml_video_post")
+                self.smoothed.data_ptr(), self.centre.data_ptr(), self.endpoints.data_ptr(), self.updated.data_ptr(), stream),
+                "nlml_video_post_ex")
         return self.smoothed, self.centre, self.endpoints
 
     def tick(self, raw: torch.Tensor):
-        """raw landmarks f32[S,468,3] of this tick (all-zero rows = no face) -> (smoothed, centre, endpoints, valid)."""
+        """raw landmarks f32[S,468,3] of this tick (all-zero rows = no face) -> (smoothed, centre, endpoints, valid).
+        valid[s] is True only where this tick was APPLIED to stream s: a face was found AND its pose is finite (a stream skipped for
+        a NaN/Inf pose keeps its previous outputs and must not be saved as a new result; the reference raises on such a frame)."""
         pose, valid = self.model.from_landmarks(raw, normalize=True, return_valid=True)
         sm, c, ep = self.post(pose, raw, valid)
-        return sm, c, ep, valid
+        return sm, c, ep, self.updated.bool()
 
 
 class GraphedTick:

@@ -28,28 +28,41 @@ void oracle_normalize_ipd(const float* raw, int64_t B, int normalize, float* out
   }
 }
 
-/* One Linear layer for one row.  order 0: k ascending; order 1: the HIP kernel's MFMA chain
- * order -- within each group of 8: k, k+4, k+1, k+5, k+2, k+6, k+3, k+7 (layout.h). */
-static void linear_row(const float* x, const float* W, const float* b, int K, int N, float* y, int order) {
+/* One Linear layer for one row.  order 0: k ascending; order 1: the HIP kernels' MFMA chain order -- within each group of 8:
+ * k, k+4, k+1, k+5, k+2, k+6, k+3, k+7 (layout.h).  blk > 0 (a multiple of 8): the K-BLOCKED sum of the f32 kernel's layers 0
+ * and 1 (encoder_heads.hip fold_block): one chain per block of blk k-values in the order above, the first from the bias, the
+ * others from +0.0, and the block sums added up in block order starting from +0.0: ((0 + s_0) + s_1) + ... */
+static float chain8(const float* w, const float* x, int k0, int k1, int K, float acc) {
+  for (; k0 + 8 <= k1; k0 += 8)
+    for (int j = 0; j < 4; ++j) {
+      acc = fmaf(w[k0 + j], x[k0 + j], acc);
+      acc = fmaf(w[k0 + 4 + j], x[k0 + 4 + j], acc);
+    }
+  if (k0 < k1) /* zero-padded tail step: padded products are exact zeros and change nothing */
+    for (int j = 0; j < 4; ++j) {
+      if (k0 + j < K) acc = fmaf(w[k0 + j], x[k0 + j], acc);
+      if (k0 + 4 + j < K) acc = fmaf(w[k0 + 4 + j], x[k0 + 4 + j], acc);
+    }
+  return acc;
+}
+
+static void linear_row(const float* x, const float* W, const float* b, int K, int N, float* y, int order, int blk) {
   for (int n = 0; n < N; ++n) {
     const float* w = W + (size_t)n * K;
-    float acc = b[n];
     if (order == 0) {
+      float acc = b[n];
       for (int k = 0; k < K; ++k) acc = fmaf(w[k], x[k], acc);
+      y[n] = acc;
+    } else if (blk <= 0) {
+      y[n] = chain8(w, x, 0, K, K, b[n]);
     } else {
-      int k0 = 0;
-      for (; k0 + 8 <= K; k0 += 8)
-        for (int j = 0; j < 4; ++j) {
-          acc = fmaf(w[k0 + j], x[k0 + j], acc);
-          acc = fmaf(w[k0 + 4 + j], x[k0 + 4 + j], acc);
-        }
-      if (k0 < K) /* zero-padded tail step: padded products are exact zeros and change nothing */
-        for (int j = 0; j < 4; ++j) {
-          if (k0 + j < K) acc = fmaf(w[k0 + j], x[k0 + j], acc);
-          if (k0 + 4 + j < K) acc = fmaf(w[k0 + 4 + j], x[k0 + 4 + j], acc);
-        }
+      float tot = 0.0f;
+      for (int k0 = 0; k0 < K; k0 += blk) {
+        const int k1 = k0 + blk < K ? k0 + blk : K;
+        tot += chain8(w, x, k0, k1, K, k0 == 0 ? b[n] : 0.0f);
+      }
+      y[n] = tot;
     }
-    y[n] = acc;
   }
 }
 
@@ -73,7 +86,7 @@ void oracle_encoder_heads_f32(const float* x, int64_t B, int F, const float* con
       int K = F;
       for (int l = 0; l < 6; ++l) {
         const int N = EN[l + 1];
-        linear_row(a, enc_w[l], enc_b[l], K, N, c, order);
+        linear_row(a, enc_w[l], enc_b[l], K, N, c, order, (order == 2 && l < 2) ? 128 : 0);   /* order 2: layers 0 and 1 K-blocked */
         if (l == 4 && pre_tanh) memcpy(pre_tanh + r * 64, c, sizeof(float) * 64);
         for (int n = 0; n < N; ++n)
           a[n] = (l < 4) ? (c[n] < 0.0f ? 0.0f : c[n]) : (l == 4 ? tanhf(c[n]) : c[n]);   /* ReLU x4 (NaN propagates, like torch.relu), Tanh, none */
@@ -87,7 +100,7 @@ void oracle_encoder_heads_f32(const float* x, int64_t B, int F, const float* con
         int Kh = 3;
         for (int l = 0; l < 5; ++l) {
           const int N = HN[l + 1];
-          linear_row(a, head_w[g * 5 + l], head_b[g * 5 + l], Kh, N, c, order);
+          linear_row(a, head_w[g * 5 + l], head_b[g * 5 + l], Kh, N, c, order, 0);
           for (int n = 0; n < N; ++n) a[n] = (l < 4) ? (c[n] < 0.0f ? 0.0f : c[n]) : c[n];
           Kh = N;
         }

@@ -81,3 +81,21 @@ def test_bench_self_launch_spawns_ranks_and_propagates_failure(tmp_path, repo_ro
     bad = subprocess.run([sys.executable, "-c", drv, "fail"], env=env, capture_output=True, text=True, timeout=300)
     assert bad.returncode == 3, (bad.returncode, bad.stderr)
     assert time.time() - t0 < 45, "the surviving rank was not stopped"
+
+
+def test_bench_self_launch_deadline_and_profiler_refusal(tmp_path, repo_root):
+    """A rank that never finishes (stuck in a collective) is terminated at the launcher's deadline and the launcher returns
+    non-zero; under a profiler preload the launcher refuses to start ranks at all (that hop is an exec after GPU init)."""
+    script = tmp_path / "hang_worker.py"
+    script.write_text("import time\ntime.sleep(120)\n")
+    drv = ("import sys; sys.path.insert(0, %r); import bench; "
+           "sys.exit(bench.spawn_ranks(2, script=%r, argv=[]))" % (repo_root, str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ROCP_TOOL_LIBRARIES", "LD_PRELOAD")}
+    import time
+    t0 = time.time()
+    res = subprocess.run([sys.executable, "-c", drv], env=dict(env, NLML_BENCH_DEADLINE_S="3"), capture_output=True, text=True, timeout=120)
+    assert res.returncode == 124, (res.returncode, res.stderr)
+    assert time.time() - t0 < 60
+    res = subprocess.run([sys.executable, "-c", drv], env=dict(env, LD_PRELOAD="/nonexistent/librocprofiler-sdk-tool.so"),   # (ld.so ignores a missing preload)
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 2 and "profiler" in res.stderr, (res.returncode, res.stderr)
