@@ -30,7 +30,8 @@ def NLML_HPE_Tester(argv=None):
     ap.add_argument("--device", default=None)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--mode", choices=["f16x2", "f32", "bf16"], default=None,
-                    help="kernel mode (default: NLML_HPE_MODE or f16x2; both f16x2 and f32 meet the 1e-4 deg bar)")
+                    help="kernel mode (default: NLML_HPE_MODE or f16x2 = the fast mode, 1.23x the reference's own distance from the exact result at "
+                         "+-45 deg poses; f32 = the strict parity mode, no further out than the reference; bf16 = throughput only, ~0.1 deg)")
     args = ap.parse_args(argv)
     warnings.filterwarnings("default")
 

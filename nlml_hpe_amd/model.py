@@ -20,12 +20,15 @@ class HIPPoseModel:
 
     def __init__(self, encoder_sd: dict, head_sds: dict, device="cuda", mode=_lib.MODE_F16X2):
         """mode (int constant or name):
-          _lib.MODE_F16X2 "f16x2"  (default) parity mode on the f16 matrix cores: every f32 operand as two f16 pieces,
-                                   <= 1e-4 deg of the reference (measured ~1e-5), 2.6x the faces/s of the f32 mode and
-                                   0.17 ms instead of 0.30 ms for a 64-face tick; a face whose activations leave f16's
-                                   range is re-evaluated in f32 inside the same launch (no input-range limit);
-          _lib.MODE_F32   "f32"    parity mode on the f32 matrix cores (same bar; no range limit; the accumulation is
-                                   the k-ordered fmaf chain, bit-identical to the C oracle);
+          _lib.MODE_F16X2 "f16x2"  (default) the fast mode, on the f16 matrix cores: every f32 operand as two f16 pieces; ~1e-5 deg
+                                   from the reference on small poses, and at the reference's operating range (poses to
+                                   +-60 deg, FX3c) 2.1e-5 / 6.7e-5 / 1.26e-4 deg from the exact result in p50 / p99 / max =
+                                   1.23x the reference's own distance, 0.05 % of the faces beyond 1e-4 deg; 3x the faces/s
+                                   of the f32 mode; a face whose activations leave f16's range is re-evaluated in f32 inside
+                                   the same launch (no input-range limit; ~40x slower if EVERY face does);
+          _lib.MODE_F32   "f32"    the strict parity mode, on the f32 matrix cores: layers 0 and 1 summed in blocks of
+                                   128 k, bit-identical to the C oracle's order 2; at the operating range 1.5e-5 / 4.9e-5 /
+                                   8.5e-5 deg from the exact result -- no further out than the reference itself; no range limit;
           _lib.MODE_BF16  "bf16"   throughput mode (bf16 weights/activations, ~0.1 deg from the reference -- never a
                                    parity result)."""
         self.input_size = weights.validate_shapes(encoder_sd, head_sds)

@@ -205,3 +205,20 @@ def test_cr_cos_is_correctly_rounded(tmp_path, repo_root):
     for i in rng.integers(0, len(y), 300):                                         # and it is within half an ulp of the exact value
         t = exact_cos(float(x[i]))
         assert abs(Decimal(float(y[i])) - t) <= Decimal(float(np.spacing(abs(y[i])))) / 2, x[i]
+
+
+def test_td_fast_order_checks_alignment_and_default_is_the_reference_order():
+    """the matrix-core order reads Wm and x with 16-byte vector loads, so the ABI refuses a misaligned base or an
+    ldx that is not a multiple of 4 in THAT order (the reference order, the default, reads dwords and accepts both).  The checks
+    run before any launch, so fake device addresses do on the CPU."""
+    L = _lib.lib()
+    a16, a4 = ctypes.c_void_p(0x10000), ctypes.c_void_p(0x10004)
+    ok = (a16, a16, 1404, None, a16, a16, 1, a16, None)
+    assert L.nlml_tucker_objective_ex(a16, a4, 1404, None, a16, a16, 1, a16, None, _lib.TD_ORDER_FAST, None) == -1
+    assert b"16-byte" in L.nlml_last_error()
+    assert L.nlml_tucker_objective_ex(a4, a16, 1404, None, a16, a16, 1, a16, None, _lib.TD_ORDER_FAST, None) == -1
+    assert L.nlml_tucker_objective_ex(a16, a16, 1405, None, a16, a16, 1, a16, None, _lib.TD_ORDER_FAST, None) == -1
+    assert L.nlml_tucker_powell_ex(a16, a4, 1404, a16, 1, None, a16, None, None, None, None, _lib.TD_ORDER_FAST, None) == -1
+    assert L.nlml_tucker_objective_ex(a16, a16, 1404, None, a16, a16, 1, a16, None, 7, None) == -1          # unknown order
+    assert L.nlml_tucker_objective_ex(a16, a16, 1404, None, a16, a16, 0, a16, None, _lib.TD_ORDER_FAST, None) == 0   # N = 0: no launch
+    del ok
