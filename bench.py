@@ -280,7 +280,7 @@ def main():
         value = world * B * args.steps / elapsed
         achieved = B * FLOP_PER_FACE[F] / (kern_ms * 1e-3) / 1e12
         traffic, traffic_source = None, None
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             tpath = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
             if not os.path.exists(tpath) or layered:
                 continue
