@@ -17,14 +17,20 @@ namespace nlml {
 
 __global__ __launch_bounds__(256) void cosine_table_kernel(const float* __restrict__ w, int64_t n,
                                                            const double* __restrict__ p, int R, double* __restrict__ out) {
+#pragma clang fp contract(off)   // without this b*w + c becomes ONE fma and the argument of the cos differs from numpy's in its
+                                 // last place (then the cos by up to 256 ulps near its zeros)
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n * R) return;
   const int64_t row = i / R;
   const int j = (int)(i % R);
   const double* q = p + 4 * j;
   // numpy evaluates b*w, + c, cos, a*, + d as separately rounded f64 operations: no fma contraction here
-  const double arg = __dadd_rn(__dmul_rn(q[1], (double)w[row]), q[2]);
-  out[i] = __dadd_rn(__dmul_rn(q[0], cr_cos(arg)), q[3]);   // correctly rounded cos (cr_cos.h): the value numpy's libm returns in all but ~1e-3 of the cases, and then 1 ulp away
+  // (plain operators under the pragma: the header's __dmul_rn / __dadd_rn are inline functions whose * and + carry THEIR
+  // translation unit's contraction licence into this one when inlined)
+  const double bw = q[1] * (double)w[row];
+  const double arg = bw + q[2];
+  const double ac = q[0] * cr_cos(arg);   // correctly rounded cos (cr_cos.h): libm's value in all but ~1e-3 of the cases, and then 1 ulp away
+  out[i] = ac + q[3];
 }
 
 // 16 x 16 outputs per workgroup, the K range staged through LDS in slices of 64 (both operands are K-contiguous)
