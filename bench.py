@@ -10,8 +10,9 @@
 One STEP = one pass of the hot path over one batch that is already resident in HBM:
 raw landmarks f32[B,468,3] -> IPD normalisation -> encoder -> 3 heads -> (yaw,pitch,roll) f32[B,3],
 one fused HIP launch per rank (nlml_landmarks_to_pose), B = 65,536 faces per GPU (weak scaling),
-F = 1404 (the reference's real feature width).  --mode picks the parity kernel: f16x2 (default: split-f16
-operands on the f16 matrix cores, f32 accumulate, ~1e-5 deg from the reference) or f32 (f32 matrix cores).  With N > 1 every
+F = 1404 (the reference's real feature width).  --mode picks the kernel: f16x2 (default: split-f16 operands on the
+f16 matrix cores, f32 accumulate; ~1e-5 deg from the reference on small poses, 1.23x the reference's own distance from the exact
+result at +-45 deg poses) or f32 (f32 matrix cores with blocked sums: the strict parity mode, 1/3 of the rate).  With N > 1 every
 step also all-gathers the [B,3] poses of all ranks over RCCL (the only collective the path has),
 on the communication stream, overlapped with the next step's compute; a second timed region of K steps without
 the collective gives `value_no_collective` (--no-collective: time only that one).
@@ -62,7 +63,7 @@ def parse():
     ap.add_argument("--path", choices=["fused", "features"], default="fused",
                     help="fused: raw landmarks in (K1+K2 in one launch); features: normalised features in (K2)")
     ap.add_argument("--mode", choices=["f16x2", "f32"], default="f16x2",
-                    help="parity kernel: f16x2 = split-f16 operands on the f16 matrix cores; f32 = f32 matrix cores")
+                    help="kernel: f16x2 = split-f16 operands on the f16 matrix cores (fast default); f32 = f32 matrix cores, blocked sums (strict parity)")
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="that many untimed steps (~1 ms each) BEFORE the W warm-up steps, so that short K/W also measure "
                          "the sustained (power-limited) rate; reported in the JSON as config.settle_ms")
@@ -302,9 +303,9 @@ def main():
                                   "frac counts the algorithmic FLOP only; at 65,536 faces the kernel runs at the board's power "
                                   "limit (clock ~1.9 GHz instead of 2.4), see DESIGN.md section 3"}
             dtype = "f16x2"
-            what = "split-f16 parity mode (two f16 pieces per f32 operand, f32 accumulate)"
+            what = "split-f16 mode (two f16 pieces per f32 operand, f32 accumulate; the fast default -- its error at the operating range is in cpu_baseline.parity_check_operating_range)"
         else:
-            peak, kernel, roof_extra, dtype, what = PEAK_F32_MFMA_TFLOPS, "encoder_heads_f32_kernel", {}, "f32", "f32 parity mode"
+            peak, kernel, roof_extra, dtype, what = PEAK_F32_MFMA_TFLOPS, "encoder_heads_f32_kernel", {}, "f32", "f32 strict parity mode (layers 0/1 summed in blocks of 128 k)"
         rec = {
             "metric": "faces_per_sec", "value": value, "unit": "faces/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
