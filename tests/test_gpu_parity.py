@@ -1278,3 +1278,28 @@ def test_reference_order_objective_on_200k_random_evaluations(tucker_art, device
     bad = int((got != ref).sum())
     _report("reference_order_200k", evaluations=n, differing=bad)
     assert bad <= 1, bad      # (0 measured; 1 allowed for a cos value where libm is not correctly rounded AND the f32 rounding flips)
+
+
+def test_bench_line_carries_the_contract_fields(repo_root, device):
+    """`python bench.py` (short run): ONE JSON line with the contract's fields, a roofline block, the CPU baseline with both live parity
+    checks -- the seed-0 sample of the timed batch and the operating-range statistics (FX3c) next to the reference's own."""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--steps", "3", "--warmup", "1", "--settle-ms", "0",
+                          "--no-extra", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=repo_root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in rec, k
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["value"] > 1e6 and "workload" in rec["config"]
+    rf = rec["roofline"]
+    assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["traffic"]
+    cb = rec["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["parity_check"]["max_abs_deg_vs_f64_oracle"] <= POSE_TOL_DEG
+    rng = cb["parity_check_operating_range"]
+    k_, r_ = rng["kernel_vs_f64_truth"], rng["reference_batched_vs_f64_truth"]
+    assert rng["faces"] == 16384 and k_["p50_deg"] <= 1.5 * r_["p50_deg"] and k_["max_deg"] <= 1.5e-4
