@@ -199,7 +199,7 @@ int nlml_tucker_objective_ex(const float* Wm, const float* x, int64_t ldx, const
  *   NLML_TD_ORDER_FAST (opt-in, ~3x the faces/s): the same algorithm on the matrix-core objective.  The minimum is flat and
  *       Powell's termination is rounding-sensitive, so the END POINT moves under ANY re-ordering of the objective's sums (scipy
  *       itself: tests/test_powell_sm.py): 6e-3 deg from scipy's on clean grid faces (FX5); on BASELINE config 3's 4,096 noisy
- *       grid faces median 8.6e-4 deg, 10 % of the faces > 0.02 deg, 0.3 % > 1 deg, max 8.7 deg.  Not a parity mode.
+ *       grid faces median 1.8e-3 deg (per face, largest of the three angles), 10 % of the faces > 0.02 deg, 0.3 % > 1 deg, max 8.7 deg.  Not a parity mode.
  */
 int nlml_tucker_powell(const float* Wm, const float* x, int64_t ldx, const double* cos_params, int64_t N,
                        const double* x0, double* result, double* fval, int32_t* nfev, int32_t* nit,

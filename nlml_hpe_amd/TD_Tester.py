@@ -63,7 +63,7 @@ def func(w, params):
 # objective bit for bit, hence scipy's own Powell trajectory and final angles (FX4, FX5) -- the DEFAULT of every function here,
 # batched or not: it is the parity mode.  "fast" (opt-in) = the GEMM form on the f64 matrix cores: objective <= 1e-12 relative,
 # ~3x the faces/s, but Powell's end point then differs from scipy's wherever the minimum is flat: 6e-3 deg on FX5's clean grid
-# faces; on BASELINE config 3's 4,096 noisy faces median 8.6e-4 deg, 10 % of the faces > 0.02 deg, 0.3 % > 1 deg, max 8.7 deg.
+# faces; on BASELINE config 3's 4,096 noisy faces median 1.8e-3 deg (per face, largest of the three angles), 10 % of the faces > 0.02 deg, 0.3 % > 1 deg, max 8.7 deg.
 ORDER_REFERENCE, ORDER_FAST = "reference", "fast"
 
 

@@ -225,7 +225,7 @@ def tucker_powell(Wm: torch.Tensor, x: torch.Tensor, cos_params: torch.Tensor, x
     """Batched Test() (TD_Tester.py:162-199): one Powell minimisation per row of x, on device.  order as in tucker_objective:
     "reference" (default, the parity mode) walks scipy's own trajectory on the reference's objective bits; "fast" (opt-in, ~3x the
     faces/s) minimises the matrix-core objective: same algorithm, but the flat minimum makes the END POINT sensitive to the last bits
-    of the objective -- 6e-3 deg from scipy on clean grid faces (FX5), and on BASELINE config 3's noisy faces median 8.6e-4 deg,
+    of the objective -- 6e-3 deg from scipy on clean grid faces (FX5), and on BASELINE config 3's noisy faces median 1.8e-3 deg (per face, largest of the three angles),
     10 % of the faces > 0.02 deg, 0.3 % > 1 deg, max 8.7 deg (bench.py extra.td_powell_fast_order reports it live).
 
     Returns dict(x=f64[N,8] (w_y,w_p,w_r radians + u_id), fun=f64[N], nfev=i32[N], nit=i32[N], status=i32[N]).
