@@ -1303,3 +1303,23 @@ def test_bench_line_carries_the_contract_fields(repo_root, device):
     rng = cb["parity_check_operating_range"]
     k_, r_ = rng["kernel_vs_f64_truth"], rng["reference_batched_vs_f64_truth"]
     assert rng["faces"] == 16384 and k_["p50_deg"] <= 1.5 * r_["p50_deg"] and k_["max_deg"] <= 1.5e-4
+
+
+def test_bench_two_rank_path_on_one_gpu(repo_root, device):
+    """The N > 1 path of bench.py -- self-launched ranks, the untimed VERIFIED all-gather, the timed steps with and without the
+    collective -- rehearsed with two ranks that share this GPU over gloo (NLML_BENCH_REHEARSAL=1: plumbing only, never a
+    measurement; on a multi-GPU node the same code runs over RCCL)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["NLML_BENCH_REHEARSAL"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--settle-ms", "0", "--batch", "2000", "--no-extra", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=repo_root, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and "REHEARSAL" in rec["data"]
+    assert rec["comm"]["verified_all_gather"] is True and rec["value_no_collective"] > 0
+    assert rec["config"]["collective"].startswith("all_gather")
