@@ -67,46 +67,48 @@ NLML_CR_HD DD dd_mul(DD a, DD b) {
   return dd_quick_two_sum(p.hi, p.lo);
 }
 
+// 1 / (2n)! and 1 / (2n+1)!, n = 0..15, as double-doubles (constexpr + fully unrolled use: immediates in the instruction stream;
+// as run-time-indexed local arrays they were 30 dependent memory reads per value)
+constexpr double CR_CC[16][2] = {
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.0000000000000p-1, 0x0.0p+0},
+    {0x1.5555555555555p-5, 0x1.5555555555555p-59},
+    {0x1.6c16c16c16c17p-10, -0x1.f49f49f49f49fp-65},
+    {0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-76},
+    {0x1.27e4fb7789f5cp-22, 0x1.cbbc05b4fa99ap-76},
+    {0x1.1eed8eff8d898p-29, -0x1.2aec959e14c06p-83},
+    {0x1.93974a8c07c9dp-37, 0x1.05d6f8a2efd1fp-92},
+    {0x1.ae7f3e733b81fp-45, 0x1.1d8656b0ee8cbp-101},
+    {0x1.6827863b97d97p-53, 0x1.eec01221a8b0bp-107},
+    {0x1.e542ba4020225p-62, 0x1.ea72b4afe3c2fp-120},
+    {0x1.0ce396db7f853p-70, -0x1.aebcdbd20331cp-124},
+    {0x1.f2cf01972f578p-80, -0x1.9ada5fcc1ab14p-135},
+    {0x1.88e85fc6a4e5ap-89, -0x1.71c37ebd16540p-143},
+    {0x1.0a18a2635085dp-98, 0x1.b9e2e28e1aa54p-153},
+    {0x1.3932c5047d60ep-108, 0x1.832b7b530a627p-162},
+};
+constexpr double CR_SC[16][2] = {
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.5555555555555p-3, 0x1.5555555555555p-57},
+    {0x1.1111111111111p-7, 0x1.1111111111111p-63},
+    {0x1.a01a01a01a01ap-13, 0x1.a01a01a01a01ap-73},
+    {0x1.71de3a556c734p-19, -0x1.c154f8ddc6c00p-73},
+    {0x1.ae64567f544e4p-26, -0x1.c062e06d1f209p-80},
+    {0x1.6124613a86d09p-33, 0x1.f28e0cc748ebep-87},
+    {0x1.ae7f3e733b81fp-41, 0x1.1d8656b0ee8cbp-97},
+    {0x1.952c77030ad4ap-49, 0x1.ac981465ddc6cp-103},
+    {0x1.2f49b46814157p-57, 0x1.2650f61dbdcb4p-112},
+    {0x1.71b8ef6dcf572p-66, -0x1.d043ae40c4647p-120},
+    {0x1.761b41316381ap-75, -0x1.3423c7d91404fp-130},
+    {0x1.3f3ccdd165fa9p-84, -0x1.58ddadf344487p-139},
+    {0x1.d1ab1c2dccea3p-94, 0x1.054d0c78aea14p-149},
+    {0x1.259f98b4358adp-103, 0x1.eaf8c39dd9bc5p-157},
+    {0x1.434d2e783f5bcp-113, 0x1.0b87b91be9affp-167},
+};
+
 NLML_CR_HD double cr_cos(double x) {
   NLML_CR_STRICT
   if (!(fabs(x) <= 1048576.0)) return cos(x);   // also NaN / Inf
-  // 1 / (2n)! and 1 / (2n+1)!, n = 0..15, as double-doubles
-  const double CC[16][2] = {
-      {0x1.0000000000000p+0, 0x0.0p+0},
-      {0x1.0000000000000p-1, 0x0.0p+0},
-      {0x1.5555555555555p-5, 0x1.5555555555555p-59},
-      {0x1.6c16c16c16c17p-10, -0x1.f49f49f49f49fp-65},
-      {0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-76},
-      {0x1.27e4fb7789f5cp-22, 0x1.cbbc05b4fa99ap-76},
-      {0x1.1eed8eff8d898p-29, -0x1.2aec959e14c06p-83},
-      {0x1.93974a8c07c9dp-37, 0x1.05d6f8a2efd1fp-92},
-      {0x1.ae7f3e733b81fp-45, 0x1.1d8656b0ee8cbp-101},
-      {0x1.6827863b97d97p-53, 0x1.eec01221a8b0bp-107},
-      {0x1.e542ba4020225p-62, 0x1.ea72b4afe3c2fp-120},
-      {0x1.0ce396db7f853p-70, -0x1.aebcdbd20331cp-124},
-      {0x1.f2cf01972f578p-80, -0x1.9ada5fcc1ab14p-135},
-      {0x1.88e85fc6a4e5ap-89, -0x1.71c37ebd16540p-143},
-      {0x1.0a18a2635085dp-98, 0x1.b9e2e28e1aa54p-153},
-      {0x1.3932c5047d60ep-108, 0x1.832b7b530a627p-162},
-  };
-  const double SC[16][2] = {
-      {0x1.0000000000000p+0, 0x0.0p+0},
-      {0x1.5555555555555p-3, 0x1.5555555555555p-57},
-      {0x1.1111111111111p-7, 0x1.1111111111111p-63},
-      {0x1.a01a01a01a01ap-13, 0x1.a01a01a01a01ap-73},
-      {0x1.71de3a556c734p-19, -0x1.c154f8ddc6c00p-73},
-      {0x1.ae64567f544e4p-26, -0x1.c062e06d1f209p-80},
-      {0x1.6124613a86d09p-33, 0x1.f28e0cc748ebep-87},
-      {0x1.ae7f3e733b81fp-41, 0x1.1d8656b0ee8cbp-97},
-      {0x1.952c77030ad4ap-49, 0x1.ac981465ddc6cp-103},
-      {0x1.2f49b46814157p-57, 0x1.2650f61dbdcb4p-112},
-      {0x1.71b8ef6dcf572p-66, -0x1.d043ae40c4647p-120},
-      {0x1.761b41316381ap-75, -0x1.3423c7d91404fp-130},
-      {0x1.3f3ccdd165fa9p-84, -0x1.58ddadf344487p-139},
-      {0x1.d1ab1c2dccea3p-94, 0x1.054d0c78aea14p-149},
-      {0x1.259f98b4358adp-103, 0x1.eaf8c39dd9bc5p-157},
-      {0x1.434d2e783f5bcp-113, 0x1.0b87b91be9affp-167},
-  };
   // argument reduction: r = x - k * pi/2, pi/2 = P1 + P2 + P3 + P4 (each exactly a double), |k| <= 2^20
   const double k = rint(x * 0x1.45f306dc9c883p-1);
   const double P1 = 0x1.921fb54442d18p+0, P2 = 0x1.1a62633145c07p-54, P3 = -0x1.f1976b7ed8fbcp-110, P4 = 0x1.4cf98e804177dp-164;
@@ -118,11 +120,16 @@ NLML_CR_HD double cr_cos(double x) {
   const DD r2 = dd_mul(r, r);
   const long long q = (long long)k & 3;         // (two's complement: also right for negative k)
   // Horner in z = r^2 on the alternating series: s_15 = -c_15, s_n = (-1)^n c_n + z * s_{n+1}, s_0 = sum_n (-1)^n c_n z^n
-  const double (*C)[2] = ((q & 1) == 0) ? CC : SC;      // +-cos(r) = sum (-1)^n r^(2n)/(2n)!;  +-sin(r) = r * sum (-1)^n r^(2n)/(2n+1)!
-  DD p = DD{-C[15][0], -C[15][1]};
+  // +-cos(r) = sum (-1)^n r^(2n)/(2n)!;  +-sin(r) = r * sum (-1)^n r^(2n)/(2n+1)!
+  // (one branch-free chain: the lanes of a wave hold different quadrants, so an if/else over the two series would run both;
+  // the coefficients are immediates selected per lane)
+  const bool odd = (q & 1) != 0;
+  DD p = DD{odd ? -CR_SC[15][0] : -CR_CC[15][0], odd ? -CR_SC[15][1] : -CR_CC[15][1]};
+#pragma unroll
   for (int n = 14; n >= 0; --n) {
     p = dd_mul(p, r2);
-    p = dd_add(DD{(n & 1) ? -C[n][0] : C[n][0], (n & 1) ? -C[n][1] : C[n][1]}, p);
+    const double sg = (n & 1) ? -1.0 : 1.0;
+    p = dd_add(DD{odd ? sg * CR_SC[n][0] : sg * CR_CC[n][0], odd ? sg * CR_SC[n][1] : sg * CR_CC[n][1]}, p);
   }
   if ((q & 1) != 0) p = dd_mul(p, r);
   // cos(x) by quadrant: q = 0: cos r, 1: -sin r, 2: -cos r, 3: sin r
