@@ -621,7 +621,7 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
                      "kernel": "tucker_powell_kernel<NLML_TD_ORDER_FAST>", "kernel_ms": dt * 1e3},
         "note": "noisy grid faces (sigma 1e-3): where the objective has several shallow minima Powell's end point is chaotic in the "
                 "last bits of the objective, so a re-ordered objective lands elsewhere on some faces"}
-    ms = time_stream(lambda: ops.tucker_objective(Wm, feats[:N], P, cp, order="reference"), 5, warm=2)
+    ms = time_stream(lambda: ops.tucker_objective(Wm, feats[:N], P, cp, order="reference"), 20, warm=5)
     evs = N / ms * 1e3
     ex["k3_tucker_objective"] = {
         "order": "reference (parity mode, the default)", "evals_per_sec": evs, "n": N,
