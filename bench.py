@@ -305,7 +305,7 @@ def main():
             dtype = "f16x2"
             what = "split-f16 mode (two f16 pieces per f32 operand, f32 accumulate; the fast default -- its error at the operating range is in cpu_baseline.parity_check_operating_range)"
         else:
-            peak, kernel, roof_extra, dtype, what = PEAK_F32_MFMA_TFLOPS, "encoder_heads_f32_kernel", {}, "f32", "f32 strict parity mode (layers 0/1 summed in blocks of 128 k)"
+            peak, kernel, roof_extra, dtype, what = PEAK_F32_MFMA_TFLOPS, "encoder_heads_f32_kernel", {}, "f32", "f32 strict parity mode (layers 0-3 summed in blocks of 128 k)"
         rec = {
             "metric": "faces_per_sec", "value": value, "unit": "faces/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

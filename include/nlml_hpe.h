@@ -68,9 +68,9 @@ int nlml_normalize_ipd(const float* raw, int64_t B, int normalize,
  *   head_w[g][i]/head_b[g][i], g<3 (yaw,pitch,roll), i<5 : model.{0,2,4,6,8}.{weight,bias},
  *                            shapes (128,3) (256,128) (128,256) (64,128) (1,64)
  * (the state-dict layout of models/Encoder.pth and models/{yaw,pitch,roll}_network.pth).
- * mode: NLML_MODE_F32 = f32 storage + f32 MFMA, layers 0 and 1 summed in blocks of 128 k (the strict parity mode: at the
+ * mode: NLML_MODE_F32 = f32 storage + f32 MFMA, layers 0 to 3 summed in blocks of 128 k (the strict parity mode: at the
  *       reference's operating range -- poses to +-60 deg, FX3c, 16,384 faces -- its distance from the exact result is
- *       1.5e-5 / 4.9e-5 / 8.5e-5 deg in p50 / p99 / max, no worse than the reference's own 1.7e-5 / 5.5e-5 / 9.9e-5);
+ *       1.25e-5 / 4.0e-5 / 8.7e-5 deg in p50 / p99 / max, no worse than the reference's own 1.7e-5 / 5.5e-5 / 9.9e-5);
  *       NLML_MODE_BF16 = bf16 weights and activations + bf16 MFMA, f32 accumulate (throughput mode:
  *       ~5x the faces/s; its error is ~0.1 deg max / 0.02 deg mean and is never claimed as parity);
  *       NLML_MODE_F16X2 = split-f16 parity mode: every f32 weight and activation is carried as two f16

@@ -26,9 +26,9 @@ class HIPPoseModel:
                                    1.23x the reference's own distance, 0.05 % of the faces beyond 1e-4 deg; 3x the faces/s
                                    of the f32 mode; a face whose activations leave f16's range is re-evaluated in f32 inside
                                    the same launch (no input-range limit; ~40x slower if EVERY face does);
-          _lib.MODE_F32   "f32"    the strict parity mode, on the f32 matrix cores: layers 0 and 1 summed in blocks of
-                                   128 k, bit-identical to the C oracle's order 2; at the operating range 1.5e-5 / 4.9e-5 /
-                                   8.5e-5 deg from the exact result -- no further out than the reference itself; no range limit;
+          _lib.MODE_F32   "f32"    the strict parity mode, on the f32 matrix cores: layers 0 to 3 summed in blocks of
+                                   128 k, bit-identical to the C oracle's order 2; at the operating range 1.25e-5 / 4.0e-5 /
+                                   8.7e-5 deg from the exact result -- no further out than the reference itself; no range limit;
           _lib.MODE_BF16  "bf16"   throughput mode (bf16 weights/activations, ~0.1 deg from the reference -- never a
                                    parity result)."""
         self.input_size = weights.validate_shapes(encoder_sd, head_sds)

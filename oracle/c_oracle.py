@@ -39,7 +39,7 @@ def normalize_ipd(raw: np.ndarray, normalize: bool = True) -> np.ndarray:
 
 def encoder_heads(x: np.ndarray, params, order: int = 2, want_latent=False, want_pre_tanh=False):
     """params: oracle.encoder_heads.Params.  order 0 = k ascending, 1 = one MFMA-order chain per output, 2 (default) = the f32
-    HIP kernel's order: MFMA-order chains with layers 0 and 1 summed in blocks of 128 k (encoder_heads.hip fold_block)."""
+    HIP kernel's order: MFMA-order chains with layers 0 to 3 summed in blocks of 128 k (encoder_heads.hip fold_block)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     B, F = x.shape
     ew = [np.ascontiguousarray(w) for w, _ in params.enc]

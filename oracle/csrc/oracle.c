@@ -30,7 +30,7 @@ void oracle_normalize_ipd(const float* raw, int64_t B, int normalize, float* out
 
 /* One Linear layer for one row.  order 0: k ascending; order 1: the HIP kernels' MFMA chain order -- within each group of 8:
  * k, k+4, k+1, k+5, k+2, k+6, k+3, k+7 (layout.h).  blk > 0 (a multiple of 8): the K-BLOCKED sum of the f32 kernel's layers 0
- * and 1 (encoder_heads.hip fold_block): one chain per block of blk k-values in the order above, the first from the bias, the
+ * to 3 (encoder_heads.hip fold_block): one chain per block of blk k-values in the order above, the first from the bias, the
  * others from +0.0, and the block sums added up in block order starting from +0.0: ((0 + s_0) + s_1) + ... */
 static float chain8(const float* w, const float* x, int k0, int k1, int K, float acc) {
   for (; k0 + 8 <= k1; k0 += 8)
@@ -86,7 +86,7 @@ void oracle_encoder_heads_f32(const float* x, int64_t B, int F, const float* con
       int K = F;
       for (int l = 0; l < 6; ++l) {
         const int N = EN[l + 1];
-        linear_row(a, enc_w[l], enc_b[l], K, N, c, order, (order == 2 && l < 2) ? 128 : 0);   /* order 2: layers 0 and 1 K-blocked */
+        linear_row(a, enc_w[l], enc_b[l], K, N, c, order, (order == 2 && l < 4) ? 128 : 0);   /* order 2: layers 0..3 K-blocked */
         if (l == 4 && pre_tanh) memcpy(pre_tanh + r * 64, c, sizeof(float) * 64);
         for (int n = 0; n < N; ++n)
           a[n] = (l < 4) ? (c[n] < 0.0f ? 0.0f : c[n]) : (l == 4 ? tanhf(c[n]) : c[n]);   /* ReLU x4 (NaN propagates, like torch.relu), Tanh, none */

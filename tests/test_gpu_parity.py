@@ -957,7 +957,7 @@ def test_fx3c_no_worse_than_the_reference_itself(mode, head_sds, golden_dir, dev
             ref_batch1_p50=r1["p50"], ref_batch1_p99=r1["p99"], ref_batch1_max=r1["max"],
             kernel_vs_ref_max=vs_ref["max"], kernel_vs_ref_frac_above=vs_ref["frac_above_1e-4"],
             ref_batch1_vs_batched_max=ref_self["max"], ref_batch1_vs_batched_frac_above=ref_self["frac_above_1e-4"])
-    # f32 kernel (layers 0 and 1 summed in blocks of 128 k): no worse than the reference in every statistic, nothing beyond 1e-4 deg.
+    # f32 kernel (layers 0 to 3 summed in blocks of 128 k): no worse than the reference in every statistic, nothing beyond 1e-4 deg.
     # split-f16 kernel: 1.23-1.27x the reference's distance from the truth (measured; its layer-0 / layer-1 accumulators round
     # 264 / 192 times per dot product at full magnitude and there is no register room for block sums), 0.05 % of the faces
     # beyond 1e-4 deg of the truth, max 1.26e-4 deg.  Bounds = measured + 20 %, not looser.
@@ -966,9 +966,10 @@ def test_fx3c_no_worse_than_the_reference_itself(mode, head_sds, golden_dir, dev
         assert k[s_] <= ratio * r[s_], (mode, s_, k, r)
     if mode == "f32":
         assert k["max"] <= POSE_TOL_DEG and k["frac_above_1e-4"] == 0.0
-        # against the reference's batched output (two f32 evaluations, each ~5e-5 deg from the truth in the tail): 0.043 % of the faces
-        # differ by more than 1e-4 deg, max 1.19e-4 deg; the reference against ITSELF (batched vs one-face calls): 0.012 %, 1.23e-4 deg
-        assert vs_ref["max"] <= 1.45e-4 and vs_ref["frac_above_1e-4"] <= 5.2e-4, (vs_ref, ref_self)
+        # against the reference's batched output (two f32 evaluations, each ~4e-5 deg from the truth in the tail): 0.012 % of the faces
+        # differ by more than 1e-4 deg, max 1.20e-4 deg -- exactly what the reference shows against ITSELF (batched vs one-face calls:
+        # 0.012 %, 1.23e-4 deg)
+        assert vs_ref["max"] <= 1.45e-4 and vs_ref["frac_above_1e-4"] <= ref_self["frac_above_1e-4"] + 2.0 / len(x), (vs_ref, ref_self)
     else:
         assert k["max"] <= 1.5e-4 and k["frac_above_1e-4"] <= 6e-4, k
         assert vs_ref["max"] <= 2.2e-4 and vs_ref["frac_above_1e-4"] <= 4.2e-3, vs_ref

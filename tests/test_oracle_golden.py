@@ -84,7 +84,7 @@ def test_fx3b_reference_range(golden_dir, head_sds):
 
 def test_fx3c_reference_range_statistics(golden_dir, head_sds):
     """FX3c (FX3b's model on 16,384 faces): how far the REFERENCE is from the f64 truth -- the yardstick of the GPU tests
-    ("no worse than the reference itself") -- and the f32 kernel's summation order restated in C (order 2: layers 0 and 1 in
+    ("no worse than the reference itself") -- and the f32 kernel's summation order restated in C (order 2: layers 0 to 3 in
     blocks of 128 k) measured against it; a single 1404-term chain per output (order 1, the kernel before round 3) is
     1.6x further out and is shown for contrast.  First 4,096 faces only (the C restatement is scalar)."""
     import fixture_models
