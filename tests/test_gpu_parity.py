@@ -1232,34 +1232,35 @@ def test_config3_reference_order_matches_scipy_on_the_c_oracle(tucker_art, devic
 
 def test_device_f_vectors_match_numpy_over_a_sweep(tucker_art, device):
     """The reference-order objective is bit-identical to the reference UP TO the cos() inside the f-vectors
-    (f = float32(a*cos(b*w+c)+d), TD_Tester.py:25-28,37).  The device evaluates a CORRECTLY ROUNDED cos (csrc/cr_cos.h); numpy's
-    is the host's libm or, on AVX-512 hosts, its SIMD loop -- accurate to an ulp, not always correctly rounded -- so the two can
-    differ by one unit in the last place of cos, and where a*cos+d nearly cancels that can flip the f32 rounding of f.  Sweep 1e6
-    angles: (1) the bare cos (row a=1,b=1,c=0,d=0) is within 1 ulp of numpy's everywhere; (2) with the shipped cosine rows the
-    number of f32 roundings that differ is counted and bounded (with the math library's cos it was 5 per 9e6; each such flip can
-    move ONE evaluation of one face off scipy's trajectory)."""
+    (f = float32(a*cos(b*w+c)+d), TD_Tester.py:25-28,37).  The device evaluates a CORRECTLY ROUNDED cos (csrc/cr_cos.h); the
+    reference's is the host libm's (numpy calls it for scalars; `math.cos` here, so that a numpy build with its own SIMD cos
+    cannot move this test) -- accurate to an ulp, not always correctly rounded -- so the two can differ by one unit in the last
+    place of cos, and where a*cos+d nearly cancels that could flip the f32 rounding of f.  Sweep 1e6 angles: (1) the bare cos (row
+    a=1,b=1,c=0,d=0) and general arguments b*w + c are within 1 ulp of libm's everywhere; (2) with the shipped cosine rows the
+    f32 roundings that differ are counted (round 2's form -- the library cos AND an fma-contracted b*w + c -- had 5 per 9e6;
+    each such flip can move ONE evaluation of one face off scipy's trajectory)."""
+    import math
     n = 1_000_000
     w = np.linspace(-1.6, 1.6, n).astype(np.float32)
+    w64 = w.astype(np.float64)
     wt = torch.from_numpy(w).to(device)
-    unit = torch.tensor([[1.0, 1.0, 0.0, 0.0]], dtype=torch.float64, device=device)
-    c_dev = ops.cosine_table(wt, unit).cpu().numpy()[:, 0]
-    c_np = np.cos(w.astype(np.float64))
-    ulp_cos = (np.abs(c_dev - c_np) / np.spacing(np.abs(c_np))).max()
-    frac_differ = float((c_dev != c_np).mean())
-    cp = _cos_params(tucker_art).reshape(9, 4)
-    got = ops.cosine_table(wt, torch.from_numpy(cp).to(device)).cpu().numpy()
-    ref = cp[None, :, 0] * np.cos(cp[None, :, 1] * w.astype(np.float64)[:, None] + cp[None, :, 2]) + cp[None, :, 3]
-    flips = int((got.astype(np.float32) != ref.astype(np.float32)).sum())
-    _report("device_cos_vs_numpy", values=9 * n, f32_roundings_that_differ=flips, cos_max_ulp=ulp_cos, cos_frac_not_equal=frac_differ)
-    assert ulp_cos <= 1.0 and frac_differ <= 0.01
-    assert flips <= 2
-    # the same for general arguments b*w + c (a fused multiply-add here would move the argument by an ulp and the cos by
-    # hundreds near its zeros: HIP's __dmul_rn / __dadd_rn do not prevent contraction)
-    for b_, c_ in ((1.388305, -1.5476), (2.93, 0.0064), (0.486, 0.0011)):
+
+    def libm_cos(arg):
+        return np.fromiter((math.cos(v) for v in arg.ravel()), dtype=np.float64, count=arg.size).reshape(arg.shape)
+    worst_ulp, frac_differ = 0.0, 0.0
+    for b_, c_ in ((1.0, 0.0), (1.388305, -1.5476), (2.93, 0.0064), (0.486, 0.0011)):
         row = torch.tensor([[1.0, b_, c_, 0.0]], dtype=torch.float64, device=device)
         got_ = ops.cosine_table(wt, row).cpu().numpy()[:, 0]
-        ref_ = np.cos(np.float64(b_) * w.astype(np.float64) + np.float64(c_))
-        assert (np.abs(got_ - ref_) <= np.spacing(np.abs(ref_))).all(), (b_, c_)
+        ref_ = libm_cos(np.float64(b_) * w64 + np.float64(c_))      # (a fused multiply-add here would move the argument by an ulp
+        worst_ulp = max(worst_ulp, float((np.abs(got_ - ref_) / np.spacing(np.abs(ref_))).max()))   # and the cos by hundreds near its zeros)
+        frac_differ = max(frac_differ, float((got_ != ref_).mean()))
+    cp = _cos_params(tucker_art).reshape(9, 4)
+    got = ops.cosine_table(wt, torch.from_numpy(cp).to(device)).cpu().numpy()
+    ref = cp[None, :, 0] * libm_cos(cp[None, :, 1] * w64[:, None] + cp[None, :, 2]) + cp[None, :, 3]
+    flips = int((got.astype(np.float32) != ref.astype(np.float32)).sum())
+    _report("device_cos_vs_libm", values=9 * n, f32_roundings_that_differ=flips, cos_max_ulp=worst_ulp, cos_frac_not_equal=frac_differ)
+    assert worst_ulp <= 1.0 and frac_differ <= 0.01
+    assert flips <= 2
 
 
 def test_reference_order_objective_on_200k_random_evaluations(tucker_art, device):
