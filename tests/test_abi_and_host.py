@@ -175,7 +175,8 @@ def test_cr_cos_is_correctly_rounded(tmp_path, repo_root):
                         np.array([0.0, 1e-300, -1e-9, np.pi / 2, np.pi, 1.5 * np.pi, -np.pi / 2, 7.0, np.inf, np.nan])])
     y = np.empty_like(x)
     lib.cr_cos_array(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), C.c_long(len(x)))
-    ref = np.cos(x[:-2])
+    import math
+    ref = np.fromiter((math.cos(v) for v in x[:-2]), dtype=np.float64, count=len(x) - 2)   # the host libm itself, whatever numpy's array loop uses
     assert np.isnan(y[-2:]).all()
     y = y[:-2]
     assert (np.abs(y - ref) <= np.spacing(np.abs(ref))).all()                       # never more than one ulp from libm
