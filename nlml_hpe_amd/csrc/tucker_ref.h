@@ -15,14 +15,18 @@
 // matrix path.  The bound is the f64 vector issue rate (16 lanes per clock and SIMD: 39.3 T operations/s at 2.4 GHz, i.e.
 // 41.5 M evaluations/s); oracle: oracle/csrc/oracle.c oracle_tucker_objective_reforder, pinned to FX4 bit for bit.
 //
-// One workgroup of 512 threads; thread t owns columns t, t+512, t+1024 (1404 of the 1536 lane slots are live: 0.914 is the
-// ceiling of any 8-wave column split, 22 wave-columns on 4 SIMDs); NE = 1..8 evaluations share every Wm load.  What keeps the
-// vector ALUs fed (round 3; the round-2 form ran at 0.46 of the issue rate):
+// One workgroup of 768 threads = 12 waves, three per SIMD; thread t owns columns t and t+768 (1404 of the 1536 lane slots are live:
+// 0.914 -- 22 wave-columns do not divide over 4 SIMDs); NE = 1..8 evaluations share every Wm load.  Three waves per SIMD because the
+// waves of a SIMD do not advance together: the oldest takes every issue slot it can use, its siblings finish one after the other, and
+// the last one runs alone -- at the 4.8 cycles per instruction ONE wave sustains -- for 1/3 of the pass (1/2 with two waves).
+// What keeps the vector ALUs fed (round 3; the round-2 form -- 512 threads x 3 columns -- ran at 0.46 of the issue rate, this one
+// at 0.58: DESIGN.md section 3 has the stamps and what bounds it now):
 //   * Wm rows come through a three-slot register ring, the loads of block (i,j,k)+2 issued before the arithmetic of block
 //     (i,j,k) (buffer loads: scalar row offset + the lane's column offset, no address arithmetic on the vector ALUs).  Round 2
 //     loaded the nine values of a block at its top and used them at once: 45 exposed L2 round trips per pass;
 //   * the innermost factor f_r[l] of every evaluation lives in scalar registers for the whole pass (it was an LDS read per (l, n)),
-//     u / f_y / f_p are re-read from a compact per-pass LDS table only when their loop level advances;
+//     u / f_y / f_p are re-read from a compact per-pass LDS table only when their loop level advances, through ONE opaque base register;
+//   * the five dependent operations of a (column, evaluation) pair advance TR_ILV evaluations x 2 columns at a time, stage by stage;
 //   * every LDS access is a real ds_ instruction (address space 3): through the generic references this non-inlined function
 //     receives they were flat_ loads, which count on vmcnt as well and so waited for the Wm prefetch just issued.
 #pragma once
