@@ -1,4 +1,4 @@
-// encoder_heads.hip -- K2: fused LandmarkEncoder + 3 AnglePredictionNetwork heads, f32 parity mode.
+// encoder_heads.hip -- K2: fused LandmarkEncoder + 3 AnglePredictionNetwork heads, f32 mode: the strict parity mode.
 //
 // Replaces CombinedAnglePredictionModel.forward (NLML_HPE_Model_Builder.py:115-126):
 //   encoder  Linear(F,1024) ReLU Linear(1024,512) ReLU Linear(512,256) ReLU Linear(256,128) ReLU
@@ -10,7 +10,7 @@
 // Shape of the computation on CDNA4 (gfx950):
 //   * one workgroup (4 waves, one per SIMD) = one tile of 64 faces through the WHOLE network;
 //   * every layer is D[neuron][face] += W[neuron][k] * act[k][face] on v_mfma_f32_32x32x2_f32
-//     (exact f32: a k-ordered fmaf chain), neurons on MFMA rows, faces on MFMA columns: the tile
+//     (exact f32: a k-ordered fmaf chain per accumulator), neurons on MFMA rows, faces on MFMA columns: the tile
 //     is two column blocks of 32 faces that SHARE every weight fragment;
 //   * waves split the NEURONS of a layer, so weights are private to a wave and stream
 //     global -> VGPR in the pre-packed fragment order of layout.h (one coalesced 1-KiB
@@ -22,8 +22,10 @@
 //   * bias is the accumulator's initial value; ReLU/Tanh are applied on the way to LDS;
 //   * layer 0's output for 64 faces (256 KB) does not fit the 160 KB LDS, so layers 0 and 1 are
 //     interleaved in two passes: pass A computes neurons 0..511 of layer 0 into LDS and layer 1
-//     accumulates over that K half; pass B does neurons 512..1023 in place and layer 1 finishes.
-//     Layer 1's 128 accumulator registers per lane stay live across pass B;
+//     accumulates over that K half; pass B does neurons 512..1023 in place and layer 1 finishes;
+//   * layers 0 to 3 sum in BLOCKS of 128 k (a chain per block, block sums added in order in a second accumulator set:
+//     fold_block): closer to the exact result than the reference's own GEMM (FX3c, tests/test_gpu_parity.py).  Layer 0 then
+//     holds two sets of 128 registers, so layer 1's set is parked in LDS (the dead h1 half image) while layer 0 runs;
 //   * layer 0 streams x through three rotating 64x32 LDS slabs (coalesced 128-B row segments; global
 //     loads 3 slabs ahead, LDS write under the previous slab's MFMAs, first operands of the next slab
 //     read before the barrier), optionally applying the IPD normalisation (FeatureExtractor.py:30-66)
