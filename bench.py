@@ -588,10 +588,14 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     def powell(order):
         ops.tucker_powell(Wm, Xg[:64], cp, order=order)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        res = ops.tucker_powell(Wm, Xg, cp, order=order)
-        torch.cuda.synchronize()
-        return res, time.perf_counter() - t0
+        best = None
+        for _ in range(2):               # one launch is the whole workload: two runs, the faster one is reported
+            t0 = time.perf_counter()
+            res = ops.tucker_powell(Wm, Xg, cp, order=order)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return res, best
 
     res_r, dt_r = powell("reference")
     nfr = res_r["nfev"].double()
