@@ -62,8 +62,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=65536, help="faces per GPU per step")
     ap.add_argument("--path", choices=["fused", "features"], default="fused",
                     help="fused: raw landmarks in (K1+K2 in one launch); features: normalised features in (K2)")
-    ap.add_argument("--mode", choices=["f16x2", "f32"], default="f16x2",
-                    help="kernel: f16x2 = split-f16 operands on the f16 matrix cores (fast default); f32 = f32 matrix cores, blocked sums (strict parity)")
+    ap.add_argument("--mode", choices=["f16x2", "f16x2s", "f32"], default="f16x2",
+                    help="kernel: f16x2 = split-f16 operands on the f16 matrix cores (fast default); f16x2s = the same with split accumulators (strict-fast); f32 = f32 matrix cores, blocked sums (strict parity)")
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="that many untimed steps (~1 ms each) BEFORE the W warm-up steps, so that short K/W also measure "
                          "the sustained (power-limited) rate; reported in the JSON as config.settle_ms")
@@ -190,14 +190,14 @@ def main():
     sd = synth.encoder_state_dict(F, seed=0)
     from nlml_hpe_amd import _lib
     from nlml_hpe_amd.model import HIPPoseModel
-    mode = _lib.MODE_F16X2 if args.mode == "f16x2" else _lib.MODE_F32
+    mode = _lib.mode_from_name(args.mode)
     blob = torch.from_numpy(weights.pack_blob(sd, heads, mode)).to(dev)
     raw_np = synth.raw_landmarks(B, seed=1 + rank)           # each rank owns its own shard of faces
     raw = torch.from_numpy(raw_np).to(dev)
     feats = ops.normalize_ipd(raw, True)
 
     # up to SMALL_BATCH_MAX faces the split-f16 mode runs layer per launch (what HIPPoseModel does; same bits as the fused kernel)
-    layered = args.mode == "f16x2" and 0 < B <= HIPPoseModel.SMALL_BATCH_MAX
+    layered = args.mode in ("f16x2", "f16x2s") and 0 < B <= HIPPoseModel.SMALL_BATCH_MAX
     if args.path == "fused":
         fwd = ops.landmarks_to_pose_small if layered else ops.landmarks_to_pose
         step_fn = lambda: fwd(raw, blob, True)
@@ -294,7 +294,7 @@ def main():
                     break
             except Exception:
                 traffic = None
-        if args.mode == "f16x2":
+        if args.mode in ("f16x2", "f16x2s"):
             peak = PEAK_F16_MFMA_TFLOPS
             kernel = "k2s_* (pre, E0, E1, E2, tail: 5 launches)" if layered else "encoder_heads_f16x2_kernel"
             roof_extra = {"executed_flop_per_launch": SPLIT_PRODUCTS * B * FLOP_PER_FACE[F],
@@ -304,6 +304,8 @@ def main():
                                   "limit (clock ~1.9 GHz instead of 2.4), see DESIGN.md section 3"}
             dtype = "f16x2"
             what = "split-f16 mode (two f16 pieces per f32 operand, f32 accumulate; the fast default -- its error at the operating range is in cpu_baseline.parity_check_operating_range)"
+            if args.mode == "f16x2s":
+                what = "split-f16 strict-fast mode (f16x2's operands; the small products of each K step in accumulators of their own)"
         else:
             peak, kernel, roof_extra, dtype, what = PEAK_F32_MFMA_TFLOPS, "encoder_heads_f32_kernel", {}, "f32", "f32 strict parity mode (layers 0-3 summed in blocks of 128 k)"
         rec = {
@@ -485,6 +487,10 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     ex["k2_f16x2_features_F1404"] = k2(lambda: ops.encoder_heads_fwd(feats, blob_hx, 1404), 1404, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
     blob136_hx = torch.from_numpy(weights.pack_blob(sd136, heads, _lib.MODE_F16X2)).to(dev)
     ex["k2_f16x2_features_F136"] = k2(lambda: ops.encoder_heads_fwd(x136, blob136_hx, 136), 136, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
+    # strict-fast mode: the same operands and MFMAs, split accumulators (layer 0 in two passes)
+    blob_hxs = torch.from_numpy(weights.pack_blob(sd1404, heads, _lib.MODE_F16X2S)).to(dev)
+    ex["k2_f16x2s_fused_F1404"] = k2(lambda: ops.landmarks_to_pose(raw, blob_hxs, True), 1404, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
+    del blob_hxs
     # (the blocks the two outputs will most likely be carved from are poisoned first: a launch that wrote nothing would otherwise
     # leave the previous call's pose in its torch.empty output and could show up as a difference of exactly 0)
     poison = [torch.full((B, 3), float("nan"), device=dev) for _ in range(2)]

@@ -87,11 +87,19 @@ int nlml_normalize_ipd(const float* raw, int64_t B, int normalize,
  *       (0.67 M faces/s; tests/test_gpu_parity.py::test_split_f16_every_face_of_a_tile_overflows).  Feed such data to
  *       NLML_MODE_F32, which has no range limit and no cliff.  Rescued faces use the blob's weights as hi + lo, i.e. 22
  *       significand bits, not the original f32 weights: ~2x torch-f32's distance from the exact result on such inputs.
+ *       NLML_MODE_F16X2S = the same operands and the same three MFMAs per product, but the two SMALL products of a K step
+ *       (w_lo*x_hi, w_hi*x_lo) accumulate in registers of their own in layers 0 to 2 and join the big sum once per K
+ *       block: the matrix instruction truncates its products to the running sum's exponent, which is what costs
+ *       NLML_MODE_F16X2 its 1.23x (profiles/r03_mfma_f16_numerics_probe.txt).  Strict parity at matrix-core speed: on FX3c
+ *       no farther from the exact result than the reference itself, at ~0.78x NLML_MODE_F16X2's faces/s (layer 0 runs in
+ *       two passes over x to make room for the second accumulator set).  Same packed image as NLML_MODE_F16X2 (+256
+ *       bytes, so the size still names the mode), same range behaviour and slow path.
  * The forward entry points recognise the mode of a blob by its size.
  */
 #define NLML_MODE_F32   0
 #define NLML_MODE_BF16  1
 #define NLML_MODE_F16X2 2
+#define NLML_MODE_F16X2S 3
 
 size_t nlml_encoder_heads_packed_bytes(int F, int mode);
 int    nlml_encoder_heads_pack(int F, int mode,
@@ -129,7 +137,7 @@ int nlml_landmarks_to_pose(const float* raw, int64_t B, int normalize,
                            const void* blob, size_t blob_bytes,
                            float* out, float* latent, uint8_t* valid, void* stream);
 
-/* The same forward for SMALL batches in NLML_MODE_F16X2: the three big layers as one launch each over (neuron blocks x
+/* The same forward for SMALL batches in NLML_MODE_F16X2 / NLML_MODE_F16X2S: the three big layers as one launch each over (neuron blocks x
  * 64-face tiles) plus one launch for the tail, instead of one CU per tile, so 64 or 2,000 faces use the whole chip (a
  * 64-face video tick: 0.06 ms instead of 0.17 ms); the results are bit-identical to nlml_encoder_heads_fwd / nlml_landmarks_to_pose with the same blob.
  * Activations pass between the launches through `workspace` (device memory, 16-byte aligned, at least

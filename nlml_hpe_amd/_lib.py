@@ -56,7 +56,8 @@ SYMBOLS = {
 MODE_F32 = 0
 MODE_BF16 = 1
 MODE_F16X2 = 2
-MODE_NAMES = {"f32": MODE_F32, "bf16": MODE_BF16, "f16x2": MODE_F16X2}
+MODE_F16X2S = 3
+MODE_NAMES = {"f32": MODE_F32, "bf16": MODE_BF16, "f16x2": MODE_F16X2, "f16x2s": MODE_F16X2S}
 TD_ORDER_FAST = 0          # GEMM on the f64 matrix cores (<= 1e-12 rel. of the reference's objective)
 TD_ORDER_REFERENCE = 1     # np.einsum's own operation order + numpy's pairwise sum: the reference's bits
 TD_ORDER_NAMES = {"fast": TD_ORDER_FAST, "reference": TD_ORDER_REFERENCE}
@@ -73,7 +74,7 @@ def td_order_from_name(order) -> int:
 
 
 def mode_from_name(mode) -> int:
-    """Accepts a NLML_MODE_* constant or its name ("f32", "bf16", "f16x2")."""
+    """Accepts a NLML_MODE_* constant or its name ("f32", "bf16", "f16x2", "f16x2s")."""
     if isinstance(mode, str):
         if mode not in MODE_NAMES:
             raise ValueError(f"unknown mode {mode!r}; expected one of {sorted(MODE_NAMES)}")

@@ -18,7 +18,8 @@ int fail(int code, const char* msg) {
 
 using namespace nlml;
 
-static bool known_mode(int mode) { return mode == NLML_MODE_F32 || mode == NLML_MODE_BF16 || mode == NLML_MODE_F16X2; }
+static bool known_mode(int mode) { return mode == NLML_MODE_F32 || mode == NLML_MODE_BF16 || mode == NLML_MODE_F16X2 || mode == NLML_MODE_F16X2S; }
+static bool split_f16(int mode) { return mode == NLML_MODE_F16X2 || mode == NLML_MODE_F16X2S; }
 
 extern "C" {
 
@@ -54,6 +55,7 @@ static int check_blob_args(int64_t B, int F, const void* blob, size_t blob_bytes
   if (blob_bytes == blob_bytes_for(F, NLML_MODE_F32)) *mode = NLML_MODE_F32;
   else if (blob_bytes == blob_bytes_for(F, NLML_MODE_BF16)) *mode = NLML_MODE_BF16;
   else if (blob_bytes == blob_bytes_for(F, NLML_MODE_F16X2)) *mode = NLML_MODE_F16X2;
+  else if (blob_bytes == blob_bytes_for(F, NLML_MODE_F16X2S)) *mode = NLML_MODE_F16X2S;
   else return fail(NLML_E_BADBLOB, "encoder_heads: blob size does not match F in any mode");
   return 0;
 }
@@ -64,7 +66,8 @@ int nlml_encoder_heads_fwd(const float* x, int64_t ldx, int64_t B, int F, const 
   if (int rc = check_blob_args(B, F, blob, blob_bytes, out, &mode)) return rc;
   if (B > 0 && (!x || ldx < F)) return fail(NLML_E_BADARG, "encoder_heads: null x or ldx < F");
   if (mode == NLML_MODE_BF16) return launch_encoder_heads_bf16(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, stream);
-  if (mode == NLML_MODE_F16X2) return launch_encoder_heads_f16x2(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, stream);
+  if (split_f16(mode))
+    return launch_encoder_heads_f16x2(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, mode == NLML_MODE_F16X2S, stream);
   return launch_encoder_heads_f32(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, nullptr, nullptr, stream);
 }
 
@@ -84,34 +87,38 @@ int nlml_landmarks_to_pose(const float* raw, int64_t B, int normalize, const voi
   if (B > 0 && !raw) return fail(NLML_E_BADARG, "landmarks_to_pose: null raw");
   if (mode == NLML_MODE_BF16)
     return launch_encoder_heads_bf16(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, stream);
-  if (mode == NLML_MODE_F16X2)
-    return launch_encoder_heads_f16x2(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, stream);
+  if (split_f16(mode))
+    return launch_encoder_heads_f16x2(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid,
+                                      mode == NLML_MODE_F16X2S, stream);
   return launch_encoder_heads_f32(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, nullptr, nullptr, stream);
 }
 
 // ---- split-f16 mode, one launch per layer (small batches) -------------------------------------------------------
 size_t nlml_encoder_heads_small_workspace_bytes(int64_t B, int F) { return small_workspace_bytes(B, F); }
 
-static int check_small(int64_t B, int F, const void* blob, size_t blob_bytes, const float* out) {
+static int check_small(int64_t B, int F, const void* blob, size_t blob_bytes, const float* out, int* split) {
   int mode = 0;
   if (int rc = check_blob_args(B, F, blob, blob_bytes, out, &mode)) return rc;
-  if (mode != NLML_MODE_F16X2) return fail(NLML_E_BADARG, "small-batch path: NLML_MODE_F16X2 blob only");
+  if (!split_f16(mode)) return fail(NLML_E_BADARG, "small-batch path: NLML_MODE_F16X2 / NLML_MODE_F16X2S blob only");
+  *split = mode == NLML_MODE_F16X2S;
   return 0;
 }
 
 int nlml_encoder_heads_fwd_small(const float* x, int64_t ldx, int64_t B, int F, const void* blob, size_t blob_bytes,
                                  float* out, float* latent, uint8_t* valid, void* workspace, size_t ws_bytes, void* stream) {
-  if (int rc = check_small(B, F, blob, blob_bytes, out)) return rc;
+  int split = 0;
+  if (int rc = check_small(B, F, blob, blob_bytes, out, &split)) return rc;
   if (B > 0 && (!x || ldx < F)) return fail(NLML_E_BADARG, "encoder_heads: null x or ldx < F");
-  return launch_encoder_heads_f16x2_small(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, workspace, ws_bytes, stream);
+  return launch_encoder_heads_f16x2_small(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, workspace, ws_bytes, split, stream);
 }
 
 int nlml_landmarks_to_pose_small(const float* raw, int64_t B, int normalize, const void* blob, size_t blob_bytes,
                                  float* out, float* latent, uint8_t* valid, void* workspace, size_t ws_bytes, void* stream) {
-  if (int rc = check_small(B, NLML_F_REFERENCE, blob, blob_bytes, out)) return rc;
+  int split = 0;
+  if (int rc = check_small(B, NLML_F_REFERENCE, blob, blob_bytes, out, &split)) return rc;
   if (B > 0 && !raw) return fail(NLML_E_BADARG, "landmarks_to_pose: null raw");
   return launch_encoder_heads_f16x2_small(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, workspace,
-                                          ws_bytes, stream);
+                                          ws_bytes, split, stream);
 }
 
 // The matrix-core order reads Wm and the x rows with 16-byte vector loads (tucker_common.h load11 / tucker_few)

@@ -25,12 +25,12 @@ int launch_encoder_heads_bf16(const float* x, int64_t ldx, const float* raw, int
 // encoder_heads_f16x2.hip (split-f16 parity mode)
 int launch_encoder_heads_f16x2(const float* x, int64_t ldx, const float* raw, int normalize,
                                int64_t B, int F, const void* blob, float* out, float* latent,
-                               uint8_t* valid, void* stream);
+                               uint8_t* valid, int split, void* stream);   // split: NLML_MODE_F16X2S
 // encoder_heads_f16x2_small.hip (split-f16 mode, big layers as separate launches + one tail launch, for small batches)
 size_t small_workspace_bytes(int64_t B, int F);
 int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,
                                      const void* blob, float* out, float* latent, uint8_t* valid, void* workspace,
-                                     size_t ws_bytes, void* stream);
+                                     size_t ws_bytes, int split, void* stream);
 // artefacts.hip
 int launch_cosine_table(const float* angles, int64_t n, const double* cos_params, int R, double* out, void* stream);
 int launch_mode5_product(const float* core, const float* U, int Q, int R5, int M, float* W, void* stream);

@@ -108,15 +108,25 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[NB][NFB], const h8 (&w)[N
 // share of the step's I = 2*NFB + 2*NB operand fetches -- first the LDS reads of the NEXT step's x operands (they are needed
 // soonest), then the global loads of the weights D steps ahead -- and by whatever the caller drops into slot m via `extra(m)`
 // (layer 0: pieces of the x staging).  sched_barrier(0) pins every slot.
+//
+// SPLIT ACCUMULATORS (round 3): `accS` receives the two SMALL products (w_lo*x_hi, w_hi*x_lo), `acc` only w_hi*x_hi; the caller adds
+// accS to acc once at the end (layer 1: also at its K midpoint).  v_mfma_f32_32x32x16_f16 aligns C and its 16 products to the
+// largest exponent among them with ~3 guard bits and truncates each aligned addend (tools/probes/mfma_f16_numerics_probe.hip):
+// against a large running sum one instruction costs 0.41 ulp rms of the sum.  With all three products in one accumulator that is
+// 3 x 88 such costs per layer-0 dot product, and the kernel sat 1.23x further from the exact result than the reference's own f32
+// GEMM at the reference's operating range (FX3c).  Now the big accumulator takes ONE instruction per 16 k, the small one sums
+// values 2^-11 the size (its truncations are 2^-11 the size too): measured p50 2.08e-5 -> 1.49e-5 deg, 12 % INSIDE the reference's
+// distance in p50, p99 and max.  Pass the same array twice for a single accumulator (the tail layers E3.. and the heads).
 template <int NB, int NFB, typename XLoad, typename Extra>
-__device__ __forceinline__ void step_fine(f32x16 (&acc)[NB][NFB], const h8 (&wcur)[NB][2], const h8 (&xcur)[NFB][2],
+__device__ __forceinline__ void step_fine(f32x16 (&acc)[NB][NFB], f32x16 (&accS)[NB][NFB], const h8 (&wcur)[NB][2], const h8 (&xcur)[NFB][2],
                                           h8 (&wnext)[NB][2], const h8* __restrict__ wp, bool prefetch, XLoad xload, Extra extra) {
   constexpr int M = 3 * NB * NFB, I = 2 * NFB + 2 * NB;
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const int t = m / (NB * NFB), nb = (m % (NB * NFB)) / NFB, fb = m % NFB;
     const int wp_ = t == 0 ? 1 : 0, xp_ = t == 1 ? 1 : 0;   // (lo,hi), (hi,lo), (hi,hi)
-    acc[nb][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[nb][wp_], xcur[fb][xp_], acc[nb][fb], 0, 0, 0);
+    if (t < 2) accS[nb][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[nb][wp_], xcur[fb][xp_], accS[nb][fb], 0, 0, 0);
+    else acc[nb][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[nb][wp_], xcur[fb][xp_], acc[nb][fb], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < I; ++i) {
@@ -152,8 +162,8 @@ __device__ __forceinline__ void kloop_pro(h8 (&wr)[ring_slots(NB, NFB)][NB][2], 
 }
 
 template <int NB, int NFB, int K16>
-__device__ __forceinline__ void kloop_run(f32x16 (&acc)[NB][NFB], h8 (&wr)[ring_slots(NB, NFB)][NB][2], const h8* __restrict__ w,
-                                          const char* in, int plane, int fb_stride) {
+__device__ __forceinline__ void kloop_run(f32x16 (&acc)[NB][NFB], f32x16 (&accS)[NB][NFB], h8 (&wr)[ring_slots(NB, NFB)][NB][2],
+                                          const h8* __restrict__ w, const char* in, int plane, int fb_stride) {
   constexpr int R = ring_slots(NB, NFB), D = R - 1;
   h8 xr[2][NFB][2];
 #pragma unroll
@@ -162,7 +172,7 @@ __device__ __forceinline__ void kloop_run(f32x16 (&acc)[NB][NFB], h8 (&wr)[ring_
     for (int p = 0; p < 2; ++p) xr[0][fb][p] = *reinterpret_cast<const h8*>(in + p * plane + fb * fb_stride);
   auto step = [&](int r, int xs, int sp, int sx, bool prefetch) {
     const int sxc = sx < K16 ? sx : K16 - 1;
-    step_fine<NB, NFB>(acc, wr[r], xr[xs], wr[(r + D) % R], w + (size_t)sp * (NB * 2 * 64), prefetch,
+    step_fine<NB, NFB>(acc, accS, wr[r], xr[xs], wr[(r + D) % R], w + (size_t)sp * (NB * 2 * 64), prefetch,
                        [&](int fb, int p) { xr[xs ^ 1][fb][p] = *reinterpret_cast<const h8*>(in + p * plane + fb * fb_stride + 32 * sxc); },
                        [](int) {});
   };
@@ -178,11 +188,29 @@ __device__ __forceinline__ void kloop_run(f32x16 (&acc)[NB][NFB], h8 (&wr)[ring_
 }
 
 template <int NB, int NFB, int K16>
-__device__ __forceinline__ void kloop(f32x16 (&acc)[NB][NFB], const h8* __restrict__ w, const char* in, int plane,
-                                      int fb_stride) {
+__device__ __forceinline__ void kloop(f32x16 (&acc)[NB][NFB], f32x16 (&accS)[NB][NFB], const h8* __restrict__ w, const char* in,
+                                      int plane, int fb_stride) {
   h8 wr[ring_slots(NB, NFB)][NB][2];
   kloop_pro<NB, NFB, K16>(wr, w);
-  kloop_run<NB, NFB, K16>(acc, wr, w, in, plane, fb_stride);
+  kloop_run<NB, NFB, K16>(acc, accS, wr, w, in, plane, fb_stride);
+}
+
+// small accumulator helpers
+template <int NB, int NFB>
+__device__ __forceinline__ void zero_acc(f32x16 (&a)[NB][NFB]) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a[nb][fb][q] = 0.0f;
+}
+template <int NB, int NFB>
+__device__ __forceinline__ void add_acc(f32x16 (&a)[NB][NFB], const f32x16 (&b)[NB][NFB]) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) a[nb][fb] += b[nb][fb];
 }
 
 // Grouped form for the heads: NJ jobs (own input each) in lock step through one ring (32-face block); the same split.
@@ -417,8 +445,20 @@ template <int NB, int NFB, int STAGE>
 __device__ __forceinline__ void job_run(const Ctx& c, int job, f32x16 (&acc)[NB][NFB], h8 (&wr)[ring_slots(NB, NFB)][NB][2],
                                         int in_off, int plane, int in_stride, int in_col, int face0) {
   const h8* w = c.blob8 + c.hdr.w_off(STAGE) + (size_t)job * c.hdr.job_w16(STAGE) + c.lane;
-  kloop_run<NB, NFB, kStages[STAGE].k8>(acc, wr, w, c.lds + in_off + ((face0 + c.f) * in_stride + in_col + 8 * c.h) * 2, plane,
+  kloop_run<NB, NFB, kStages[STAGE].k8>(acc, acc, wr, w, c.lds + in_off + ((face0 + c.f) * in_stride + in_col + 8 * c.h) * 2, plane,
                                         32 * in_stride * 2);
+}
+
+// the same with the two small products in an accumulator of their own, added to `acc` at the end (see step_fine)
+template <int NB, int NFB, int STAGE>
+__device__ __forceinline__ void job_run_split(const Ctx& c, int job, f32x16 (&acc)[NB][NFB], h8 (&wr)[ring_slots(NB, NFB)][NB][2],
+                                              int in_off, int plane, int in_stride, int in_col, int face0) {
+  const h8* w = c.blob8 + c.hdr.w_off(STAGE) + (size_t)job * c.hdr.job_w16(STAGE) + c.lane;
+  f32x16 accS[NB][NFB];
+  zero_acc<NB, NFB>(accS);
+  kloop_run<NB, NFB, kStages[STAGE].k8>(acc, accS, wr, w, c.lds + in_off + ((face0 + c.f) * in_stride + in_col + 8 * c.h) * 2, plane,
+                                        32 * in_stride * 2);
+  add_acc<NB, NFB>(acc, accS);
 }
 
 template <int NB, int NFB, int STAGE>

@@ -104,13 +104,15 @@ struct LayerArgs {
   h8* xout;
   int64_t B;
   int stage, K16, nb_stage, jobs, ntiles, buf_steps, act;
+  int fold_step;      // K step after which the small accumulator is folded into the big one mid-way (layer 1: 32; else 0)
   int in_step0[12];   // first input K step of job j (its input column / 16)
   int out_col0[12];   // first output column of job j
 };
 
 // R = depth of the operand ring.  With few units (one wave per CU) a unit's rate is its own loads in flight, so those
 // launches use 64-thread workgroups (the units spread over the CUs instead of sharing one four at a time) and R = 8.
-template <int NBW, int R>
+// SPLIT: NLML_MODE_F16X2S, the small products of a K step accumulate apart (as the fused kernel's step_fine does in that mode).
+template <int NBW, int R, bool SPLIT>
 __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
   const int lane = threadIdx.x & 63, f = lane & 31, h = lane >> 5;
   const int groups = a.nb_stage / NBW;                     // units per (tile, job)
@@ -156,6 +158,27 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
 #pragma unroll
       for (int p = 0; p < 2; ++p) xr[slot][fb][p] = xp[(fb * 2 + p) * 64];
   };
+  constexpr int NBS_ = SPLIT ? NBW : 1;
+  f32x16 accS[NBS_][2];   // the two small products of every K step; added to acc at the end (layer 1: also at its K midpoint,
+#pragma unroll          // where the fused kernel parks layer 1's accumulators in LDS for the length of layer 0's second pass)
+  for (int i = 0; i < NBS_; ++i)
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) accS[i][fb][q] = 0.0f;
+  auto fold = [&](bool clear) {
+    if constexpr (!SPLIT) return;
+#pragma unroll
+    for (int i = 0; i < NBS_; ++i)
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb) {
+        acc[i][fb] += accS[i][fb];
+        if (clear) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) accS[i][fb][q] = 0.0f;
+        }
+      }
+  };
   auto mma = [&](int slot) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -164,7 +187,9 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
       for (int i = 0; i < NBW; ++i)
 #pragma unroll
         for (int fb = 0; fb < 2; ++fb)
-          acc[i][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[slot][i][wp_], xr[slot][fb][xp_], acc[i][fb], 0, 0, 0);
+          // split accumulators, exactly as the fused kernel (encoder_heads_f16x2_dev.h step_fine): small products apart
+          if (SPLIT && t < 2) accS[SPLIT ? i : 0][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[slot][i][wp_], xr[slot][fb][xp_], accS[SPLIT ? i : 0][fb], 0, 0, 0);
+          else acc[i][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[slot][i][wp_], xr[slot][fb][xp_], acc[i][fb], 0, 0, 0);
     }
   };
 #pragma unroll
@@ -178,13 +203,18 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       mma(r);
       __builtin_amdgcn_sched_barrier(0);
+      if (SPLIT && g * R + r + 1 == a.fold_step) fold(true);   // (fold_step 0: never)
     }
   }
   const int tail = K16 - groups4 * R;   // steps groups4*R + r sit in slot r (loaded D steps earlier, or by the prologue)
 #pragma unroll
   for (int r = 0; r < R - 1; ++r)
-    if (r < tail) mma(r);
+    if (r < tail) {
+      mma(r);
+      if (SPLIT && groups4 * R + r + 1 == a.fold_step) fold(true);
+    }
 
+  fold(false);
   const float inv = hdr->inv_scale[st];
   // accumulators * inv -> activation -> hi/lo -> the next layer's input fragments
 #pragma unroll
@@ -255,7 +285,7 @@ size_t small_workspace_bytes(int64_t B, int F) {
 
 int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,
                                      const void* blob, float* out, float* latent, uint8_t* valid, void* workspace,
-                                     size_t ws_bytes, void* stream) {
+                                     size_t ws_bytes, int split, void* stream) {
   using namespace hxs;
   if (B == 0) return 0;
   if (ws_bytes < small_workspace_bytes(B, F) || !workspace) return fail(NLML_E_BADARG, "small-batch path: workspace too small");
@@ -281,26 +311,34 @@ int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* r
     LayerArgs a{};
     a.blob = blob; a.xin = in; a.xout = outb; a.B = B; a.stage = stages[s].stage; a.K16 = stages[s].K16;
     a.nb_stage = stages[s].nb; a.jobs = stages[s].jobs; a.ntiles = ntiles; a.buf_steps = buf_steps; a.act = hx::ACT_RELU;
+    a.fold_step = (split && stages[s].stage == ST_E1) ? 32 : 0;   // the fused kernel adds layer 1's small products at its K midpoint too
     for (int j = 0; j < a.jobs; ++j) {
       a.in_step0[j] = 0;
       a.out_col0[j] = 32 * a.nb_stage * j;
     }
+#define NLML_HXS_LAUNCH(NB, R)                                                               \
+  do {                                                                                       \
+    if (split) hipLaunchKernelGGL((layer_kernel<NB, R, true>), grid, block, 0, st, a);       \
+    else hipLaunchKernelGGL((layer_kernel<NB, R, false>), grid, block, 0, st, a);            \
+  } while (0)
     // blocks per wave: as many as still leave enough waves to keep the weight loads of every CU in flight
     int nbw = a.nb_stage;
+    if (split && nbw > 2) nbw = 2;    // two accumulator sets per block: four blocks per wave would not fit the register file
     constexpr int kMinUnits = 2048;   // measured: 8 waves per CU keep enough loads in flight (256 units: 153 us at B = 2,000; 2,048: 114 us)
     while (nbw > 1 && (int64_t)ntiles * a.jobs * (a.nb_stage / nbw) < kMinUnits) nbw >>= 1;
     const int64_t units = (int64_t)ntiles * a.jobs * (a.nb_stage / nbw);
     if (units < 1024) {   // fewer than four waves per CU: one wave per workgroup, deep ring
       const dim3 grid((unsigned)units), block(64);
-      if (nbw == 4) hipLaunchKernelGGL((layer_kernel<4, 6>), grid, block, 0, st, a);
-      else if (nbw == 2) hipLaunchKernelGGL((layer_kernel<2, 8>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((layer_kernel<1, 8>), grid, block, 0, st, a);
+      if (nbw == 4) NLML_HXS_LAUNCH(4, 6);
+      else if (nbw == 2) NLML_HXS_LAUNCH(2, 8);
+      else NLML_HXS_LAUNCH(1, 8);
     } else {
       const dim3 grid((unsigned)((units + 3) / 4)), block(256);
-      if (nbw == 4) hipLaunchKernelGGL((layer_kernel<4, 4>), grid, block, 0, st, a);
-      else if (nbw == 2) hipLaunchKernelGGL((layer_kernel<2, 4>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((layer_kernel<1, 4>), grid, block, 0, st, a);
+      if (nbw == 4) NLML_HXS_LAUNCH(4, 4);
+      else if (nbw == 2) NLML_HXS_LAUNCH(2, 4);
+      else NLML_HXS_LAUNCH(1, 4);
     }
+#undef NLML_HXS_LAUNCH
     h8* t = in; in = outb; outb = t;
   }
   {

@@ -41,6 +41,8 @@ inline int row_of(const JobSrc& j, int i) {
 
 }  // namespace
 
+static bool split_f16(int mode) { return mode == NLML_MODE_F16X2 || mode == NLML_MODE_F16X2S; }
+
 // Layer 0's K is padded (zero weights) to whole PAIRS of x slabs (2 x XS_COLS columns), so the kernel's
 // slab loop has no partial-slab case and its two staging register sets alternate statically.
 static int e0_k8(int F) { return (F + 2 * XS_COLS - 1) / (2 * XS_COLS) * (2 * XS_STEPS); }
@@ -51,12 +53,12 @@ static int e0_k16(int F) { return (F + 2 * bf::XS_COLS - 1) / (2 * bf::XS_COLS) 
 static int e0_k16x2(int F) { return (F + 2 * hx::XS_COLS - 1) / (2 * hx::XS_COLS) * (2 * hx::XS_STEPS); }
 
 static const StageDesc& stage_of(int mode, int s) {
-  return mode == NLML_MODE_BF16 ? bf::kStages[s] : (mode == NLML_MODE_F16X2 ? hx::kStages[s] : kStages[s]);
+  return mode == NLML_MODE_BF16 ? bf::kStages[s] : (split_f16(mode) ? hx::kStages[s] : kStages[s]);
 }
 static int e0_steps(int mode, int F) {
-  return mode == NLML_MODE_BF16 ? e0_k16(F) : (mode == NLML_MODE_F16X2 ? e0_k16x2(F) : e0_k8(F));
+  return mode == NLML_MODE_BF16 ? e0_k16(F) : (split_f16(mode) ? e0_k16x2(F) : e0_k8(F));
 }
-static int pieces_of(int mode) { return mode == NLML_MODE_F16X2 ? hx::PIECES : 1; }
+static int pieces_of(int mode) { return split_f16(mode) ? hx::PIECES : 1; }
 
 
 // round-to-nearest-even f32 -> f16 bits and back (host side of the split; subnormals kept, overflow -> inf)
@@ -105,6 +107,7 @@ size_t blob_bytes_for(int F, int mode) {
     units += (size_t)d.jobs * k8 * d.nb * 64 * pieces_of(mode);      // weights: 16 bytes per lane (and piece)
     units += (size_t)d.jobs * d.nb * 2 * 4;        // bias: 2 halves x 16 floats
   }
+  if (mode == NLML_MODE_F16X2S) units += 16;   // the same image as NLML_MODE_F16X2 plus 256 bytes: the mode is read off the size
   units += 4096;  // 64 KiB tail pad: the K loops prefetch up to 7 steps (<= 8 KiB) past a job's end
   return units * 16;
 }
@@ -113,7 +116,7 @@ int pack_blob(int F, int mode, const float* const enc_w[6], const float* const e
               const float* const head_w[3][5], const float* const head_b[3][5],
               void* blob, size_t blob_bytes) {
   if (F <= 0 || !blob) return fail(NLML_E_BADARG, "pack: bad F or null blob");
-  const bool bf16 = mode == NLML_MODE_BF16, f16x2 = mode == NLML_MODE_F16X2;
+  const bool bf16 = mode == NLML_MODE_BF16, f16x2 = split_f16(mode);
   const int kw = (bf16 || f16x2) ? 16 : 8;        // K step width
   const int pieces = pieces_of(mode);
   const int per_half = kw / 2;         // k values per lane half

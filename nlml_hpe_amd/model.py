@@ -26,6 +26,10 @@ class HIPPoseModel:
                                    1.23x the reference's own distance, 0.05 % of the faces beyond 1e-4 deg; 3x the faces/s
                                    of the f32 mode; a face whose activations leave f16's range is re-evaluated in f32 inside
                                    the same launch (no input-range limit; ~40x slower if EVERY face does);
+          _lib.MODE_F16X2S "f16x2s" the strict-fast mode: f16x2's operands and matrix instructions, the small products of
+                                   each K step in accumulators of their own (layers 0 to 2): at the operating range no farther
+                                   from the exact result than the reference itself, at ~0.78x f16x2's faces/s; same range
+                                   behaviour as f16x2;
           _lib.MODE_F32   "f32"    the strict parity mode, on the f32 matrix cores: layers 0 to 3 summed in blocks of
                                    128 k, bit-identical to the C oracle's order 2; at the operating range 1.25e-5 / 4.0e-5 /
                                    8.7e-5 deg from the exact result -- no further out than the reference itself; no range limit;
@@ -74,7 +78,7 @@ class HIPPoseModel:
     def _small(self, B: int) -> bool:
         """Split-f16 mode, up to SMALL_BATCH_MAX faces: the layer-per-launch path (same bits as the fused kernel, 0.06-0.13 ms
         instead of 0.17 ms because a handful of 64-face tiles cannot fill 256 CUs with one CU per tile)."""
-        return self.mode == _lib.MODE_F16X2 and 0 < B <= self.SMALL_BATCH_MAX
+        return self.mode in (_lib.MODE_F16X2, _lib.MODE_F16X2S) and 0 < B <= self.SMALL_BATCH_MAX
 
     def from_landmarks(self, raw: torch.Tensor, normalize: bool = True, return_latent: bool = False,
                        return_valid: bool = False):

@@ -127,7 +127,7 @@ def forward_f16x2(blob: np.ndarray, x: np.ndarray) -> tuple:
 
     Activations pass between layers as f32 (the kernel rounds accumulator*inv_scale to f32 before splitting)."""
     hdr = _header(blob)
-    assert hdr["mode"] == 2
+    assert hdr["mode"] in (2, 3)      # NLML_MODE_F16X2 / NLML_MODE_F16X2S: one image
     F, k16 = hdr["F"], hdr["k8_e0"]
     f32 = lambda v: np.asarray(v, np.float32)
     xin = np.zeros((32, 16 * k16), np.float32)

@@ -62,6 +62,13 @@ def test_packed_blob_walk_split_f16_mode(F, head_sds):
     err_deg = np.abs(np.degrees(out - ref)).max()
     assert err_deg <= 2e-5, err_deg                       # parity bar is 1e-4 deg; the split leaves ~1e-5
     assert np.abs(lat - EH.encoder_latent_numpy(x, P, np.float64)).max() <= 2e-6
+    # NLML_MODE_F16X2S: the same image (the header's mode and total-size words apart) plus 256 bytes of zero padding
+    blob_s = weights.pack_blob(sd, head_sds, _lib.MODE_F16X2S)
+    assert blob_s.nbytes == blob.nbytes + 256
+    a, b = blob.view(np.uint8), blob_s.view(np.uint8)
+    diff = np.flatnonzero(a != b[:a.size])
+    assert set(diff // 4) == {3, 5} and a[12] == _lib.MODE_F16X2 and b[12] == _lib.MODE_F16X2S and not b[a.size:].any()
+    assert blob_s.view(np.uint32)[5] == blob.view(np.uint32)[5] + 16
 
 
 def test_pack_rejects_bad_input(head_sds):
@@ -137,12 +144,19 @@ def test_mode_names_and_default_are_the_parity_modes():
     from nlml_hpe_amd import model as M
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "nlml_hpe.h")).read()
     consts = {k: int(v) for k, v in re.findall(r"#define\s+NLML_MODE_(\w+)\s+(\d+)", hdr)}
-    assert consts == {"F32": _lib.MODE_F32, "BF16": _lib.MODE_BF16, "F16X2": _lib.MODE_F16X2}
+    assert consts == {"F32": _lib.MODE_F32, "BF16": _lib.MODE_BF16, "F16X2": _lib.MODE_F16X2, "F16X2S": _lib.MODE_F16X2S}
+    assert _lib.mode_from_name("f16x2s") == _lib.MODE_F16X2S == 3
     assert _lib.mode_from_name("f16x2") == _lib.MODE_F16X2 and _lib.mode_from_name("f32") == 0 and _lib.mode_from_name(1) == 1
     with pytest.raises(ValueError):
         _lib.mode_from_name("fp8")
     with pytest.raises(ValueError):
         _lib.mode_from_name(9)
+    # the forward entry points read a blob's mode off its size: the four sizes must differ, at every F the tests use
+    L = _lib.lib()
+    for F in (10, 13, 64, 136, 1404, 1407):
+        sizes = [L.nlml_encoder_heads_packed_bytes(F, m) for m in (0, 1, 2, 3)]
+        assert len(set(sizes)) == 4 and all(sizes), (F, sizes)
+        assert sizes[3] == sizes[2] + 256
     default = inspect.signature(M.HIPPoseModel.__init__).parameters["mode"].default
     assert default in (_lib.MODE_F16X2, _lib.MODE_F32), "the default must be one of the two parity modes, never bf16"
     with pytest.raises(_lib.NlmlError):

@@ -553,13 +553,17 @@ def test_graphed_video_tick_matches_eager(head_sds, device):
 
 
 # ---- split-f16 parity mode (NLML_MODE_F16X2) ---------------------------------------------------------------------
-def _blob_hx(sd, head_sds, device):
+HX_MODES = ["f16x2", "f16x2s"]     # the fast mode and the strict-fast mode (split accumulators): same operands, same tests
+
+
+def _blob_hx(sd, head_sds, device, hx="f16x2"):
     from nlml_hpe_amd import _lib
-    return torch.from_numpy(weights.pack_blob(sd, head_sds, _lib.MODE_F16X2)).to(device)
+    return torch.from_numpy(weights.pack_blob(sd, head_sds, _lib.mode_from_name(hx))).to(device)
 
 
+@pytest.mark.parametrize("hx", HX_MODES)
 @pytest.mark.parametrize("F,B", [(1404, 1), (1404, 31), (1404, 33), (1404, 1000), (136, 77), (64, 50), (10, 40), (1407, 65)])
-def test_split_f16_mode_vs_oracle(F, B, head_sds, device):
+def test_split_f16_mode_vs_oracle(F, B, hx, head_sds, device):
     """NLML_MODE_F16X2 is a PARITY mode: same 1e-4 degree bar as the f32 kernel (tolerance: POSE_TOL_DEG, absolute,
     against the f64 arithmetic truth and against the f32 CPU restatement of the reference)."""
     sd = synth.encoder_state_dict(F, seed=3)
@@ -568,16 +572,17 @@ def test_split_f16_mode_vs_oracle(F, B, head_sds, device):
     ref64 = EH.forward_numpy(x, P, np.float64)
     ref32 = EH.forward_numpy(x, P, np.float32)
     lat64 = EH.encoder_latent_numpy(x, P, np.float64)
-    out, lat = ops.encoder_heads_fwd(torch.from_numpy(x).to(device), _blob_hx(sd, head_sds, device), F, return_latent=True)
+    out, lat = ops.encoder_heads_fwd(torch.from_numpy(x).to(device), _blob_hx(sd, head_sds, device, hx), F, return_latent=True)
     out, lat = out.cpu().numpy(), lat.cpu().numpy()
     e64 = np.degrees(np.abs(out - ref64).max())
     e32 = np.degrees(np.abs(out - ref32).max())
-    _report(f"split_f16_vs_oracle_F{F}_B{B}", hip_vs_f64_deg=e64, hip_vs_f32_deg=e32, latent_abs=np.abs(lat - lat64).max())
+    _report(f"split_f16_vs_oracle_{hx}_F{F}_B{B}", hip_vs_f64_deg=e64, hip_vs_f32_deg=e32, latent_abs=np.abs(lat - lat64).max())
     assert e64 <= POSE_TOL_DEG and e32 <= POSE_TOL_DEG, (e64, e32)
     assert np.abs(lat - lat64).max() <= 5e-6
 
 
-def test_split_f16_mode_golden_and_blob_walk(head_sds, golden_dir, device):
+@pytest.mark.parametrize("hx", HX_MODES)
+def test_split_f16_mode_golden_and_blob_walk(hx, head_sds, golden_dir, device):
     """FX3 golden vectors (generated by the reference itself) within the bar, and the kernel agrees with the numpy
     walk of its own blob (tests/blob_emulator.py forward_f16x2: same pieces, same three products) far more tightly."""
     import blob_emulator as BE
@@ -587,24 +592,25 @@ def test_split_f16_mode_golden_and_blob_walk(head_sds, golden_dir, device):
         sd = synth.encoder_state_dict(F, seed=0)
         x = synth.features(256, F, seed=1)
         x[7] = 0.0
-        blob_np = weights.pack_blob(sd, head_sds, _lib.MODE_F16X2)
+        blob_np = weights.pack_blob(sd, head_sds, _lib.mode_from_name(hx))
         out, valid = ops.encoder_heads_fwd(torch.from_numpy(x).to(device), torch.from_numpy(blob_np).to(device), F, return_valid=True)
         out = out.cpu().numpy()
         err = np.degrees(np.abs(out - g[f"rad_F{F}"]).max())
         emu, _ = BE.forward_f16x2(blob_np, x[32:64])
         e_emu = np.degrees(np.abs(out[32:64] - emu).max())
-        _report(f"split_f16_fx3_F{F}", max_abs_deg=err, vs_blob_walk_deg=e_emu)
+        _report(f"split_f16_fx3_{hx}_F{F}", max_abs_deg=err, vs_blob_walk_deg=e_emu)
         assert err <= POSE_TOL_DEG, err
         assert e_emu <= 2e-5, e_emu            # f32 vs f64 accumulation of identical products
         v = valid.cpu().numpy()
         assert not v[7] and v.sum() == 255
 
 
-def test_split_f16_fused_landmarks_and_valid_mask(head_sds, device):
+@pytest.mark.parametrize("hx", HX_MODES)
+def test_split_f16_fused_landmarks_and_valid_mask(hx, head_sds, device):
     """Fused landmarks->pose in split-f16 mode: IPD normalisation stays exact (f64 division as in K1), so fused ==
     normalise + forward bit for bit; validity mask and partial tiles as in the f32 mode."""
     sd = synth.encoder_state_dict(1404, seed=0)
-    blob = _blob_hx(sd, head_sds, device)
+    blob = _blob_hx(sd, head_sds, device, hx)
     raw = synth.raw_landmarks(131, seed=17)
     raw[3] = np.array([0.25, 0.5, 0.75], np.float32)
     raw[64] = 0.0
@@ -626,12 +632,13 @@ def test_split_f16_fused_landmarks_and_valid_mask(head_sds, device):
     assert ok.sum() == 128
 
 
-def test_split_f16_full_batch_65536_properties(head_sds, device):
+@pytest.mark.parametrize("hx", HX_MODES)
+def test_split_f16_full_batch_65536_properties(hx, head_sds, device):
     """BASELINE.json size in split-f16 mode: batch-position independence (bit-exact), sampled rows within 1e-4 deg of
     the f64 oracle, and agreement with the f32 parity kernel on every one of the 65,536 faces within the same bar."""
     F, B = 1404, 65536
     sd = synth.encoder_state_dict(F, seed=0)
-    blob = _blob_hx(sd, head_sds, device)
+    blob = _blob_hx(sd, head_sds, device, hx)
     x = synth.features(B, F, seed=42)
     xt = torch.from_numpy(x).to(device)
     full = ops.encoder_heads_fwd(xt, blob, F)
@@ -642,18 +649,19 @@ def test_split_f16_full_batch_65536_properties(head_sds, device):
     err = np.degrees(np.abs(full[it].cpu().numpy() - ref).max())
     f32 = ops.encoder_heads_fwd(xt, _blob(sd, head_sds, device), F)
     d = torch.rad2deg((full - f32).abs()).max().item()
-    _report("split_f16_full_batch", sampled_vs_f64_deg=err, all_faces_vs_f32_kernel_deg=d)
+    _report(f"split_f16_full_batch_{hx}", sampled_vs_f64_deg=err, all_faces_vs_f32_kernel_deg=d)
     assert err <= POSE_TOL_DEG and d <= POSE_TOL_DEG, (err, d)
     assert torch.equal(ops.encoder_heads_fwd(xt[:B - 1], blob, F), full[:B - 1])
 
 
-def test_split_f16_nan_inf_stay_loud_and_f16_overflow_is_rescued(head_sds, device):
+@pytest.mark.parametrize("hx", HX_MODES)
+def test_split_f16_nan_inf_stay_loud_and_f16_overflow_is_rescued(hx, head_sds, device):
     """NaN/Inf inputs stay in their face (non-finite pose, as in the reference).  A FINITE input whose activations leave f16's
     range (|v| >= 65520) is re-evaluated by the kernel's f32 slow path (encoder_heads_f16x2_rescue.h): finite, accurate, and
     the other faces of the tile keep their bits."""
     F = 1404
     sd = synth.encoder_state_dict(F, seed=0)
-    blob = _blob_hx(sd, head_sds, device)
+    blob = _blob_hx(sd, head_sds, device, hx)
     x = synth.features(200, F, seed=23)
     clean = ops.encoder_heads_fwd(torch.from_numpy(x).to(device), blob, F)
     bad = x.copy()
@@ -675,7 +683,7 @@ def test_split_f16_nan_inf_stay_loud_and_f16_overflow_is_rescued(head_sds, devic
         ref = EH.forward_numpy(bad[r:r + 1], P, np.float64)
         ref32 = EH.forward_torch(bad[r:r + 1], P)
         e = np.degrees(np.abs(out[r].cpu().numpy() - ref[0]).max())
-        _report(f"split_f16_rescue_row{r}", max_abs_deg=e, torch_f32_vs_f64_deg=np.degrees(np.abs(np.asarray(ref32) - ref).max()))
+        _report(f"split_f16_rescue_{hx}_row{r}", max_abs_deg=e, torch_f32_vs_f64_deg=np.degrees(np.abs(np.asarray(ref32) - ref).max()))
         assert torch.isfinite(out[r]).all() and e <= POSE_TOL_DEG, (r, e)
         assert np.abs(lat[r].cpu().numpy() - EH.encoder_latent_numpy(bad[r:r + 1], P, np.float64)[0]).max() <= 5e-6
     # the layer-per-launch path takes the same slow path: identical bits
@@ -684,7 +692,7 @@ def test_split_f16_nan_inf_stay_loud_and_f16_overflow_is_rescued(head_sds, devic
     assert torch.equal(out_s[fin], out[fin]) and torch.equal(torch.isfinite(out_s).all(dim=1), fin)
 
 
-@pytest.mark.parametrize("mode", ["f16x2", "f32"])
+@pytest.mark.parametrize("mode", ["f16x2", "f16x2s", "f32"])
 @pytest.mark.parametrize("normalize", [True, False])
 def test_fx1_degenerate_faces_through_the_fused_path(mode, normalize, head_sds, golden_dir, device):
     """FX1's faces -- ipd == 0 (the reference's 1e-6 branch, FeatureExtractor.py:47-48: features ~1e6), near-degenerate ipd,
@@ -710,18 +718,19 @@ def test_fx1_degenerate_faces_through_the_fused_path(mode, normalize, head_sds, 
     _report(f"fx1_fused_{mode}_norm{int(normalize)}", max_abs_deg=err.max(), max_abs_deg_wo_face5=np.delete(err, 5).max(),
             torch_f32_vs_f64_deg=np.degrees(np.abs(ref32 - truth).max()))
     assert (err <= tol).all(), err
-    if mode == "f16x2":
+    if mode in HX_MODES:
         small = ops.landmarks_to_pose_small(raw, blob, normalize)
         assert torch.equal(small, torch.from_numpy(pose).to(device))
         two_step = ops.encoder_heads_fwd(torch.from_numpy(feats).to(device), blob, 1404)
         assert torch.equal(two_step, torch.from_numpy(pose).to(device))     # fused == K1 -> K2, slow-path faces included
 
 
-def test_split_f16_strided_unaligned_input_and_determinism(head_sds, device):
+@pytest.mark.parametrize("hx", HX_MODES)
+def test_split_f16_strided_unaligned_input_and_determinism(hx, head_sds, device):
     """Row stride > F, a start that is not 16-byte aligned (scalar-load path), and bit-identical repeat launches."""
     F = 136
     sd = synth.encoder_state_dict(F, seed=0)
-    blob = _blob_hx(sd, head_sds, device)
+    blob = _blob_hx(sd, head_sds, device, hx)
     xfull = synth.features(100, 200, seed=4)
     P = EH.Params(sd, head_sds)
     for off in (8, 3):                                  # 32-byte offset (vector path) and 12-byte offset (scalar path)
@@ -735,7 +744,7 @@ def test_split_f16_strided_unaligned_input_and_determinism(head_sds, device):
     assert torch.equal(ops.encoder_heads_fwd(xa, blob, F), ops.encoder_heads_fwd(torch.from_numpy(xfull).to(device)[:, 3:3 + F], blob, F))
 
 
-@pytest.mark.parametrize("mode", ["f16x2", "f32"])
+@pytest.mark.parametrize("mode", ["f16x2", "f16x2s", "f32"])
 def test_repeat_launches_are_bit_identical_under_load(mode, head_sds, device):
     """200 back-to-back launches (all 256 CUs busy, clocks and power moving) of the fused path on the same 16,384 faces
     return the same bits every time: the LDS slab rotation, the two-pass layer 0 and the prefetch rings have no
@@ -815,13 +824,14 @@ def test_fx9_td_gradient_on_device(tucker_art, golden_dir, device):
 
 
 # ---- split-f16 mode, one launch per layer (small batches) ---------------------------------------------------------
+@pytest.mark.parametrize("hx", HX_MODES)
 @pytest.mark.parametrize("F,B", [(1404, 1), (1404, 64), (1404, 65), (1404, 200), (1404, 2000), (136, 77), (13, 5), (1407, 130)])
-def test_small_batch_path_is_bit_identical_to_the_fused_kernel(F, B, head_sds, device):
+def test_small_batch_path_is_bit_identical_to_the_fused_kernel(F, B, hx, head_sds, device):
     """nlml_encoder_heads_fwd_small runs every layer as its own launch over (neuron blocks x tiles) with activations in a
     workspace; per output it issues the same MFMAs in the same order as the fused split-f16 kernel, so pose, latent and
     validity must be the same bits (and with them every parity result of the fused kernel carries over)."""
     sd = synth.encoder_state_dict(F, seed=3)
-    blob = _blob_hx(sd, head_sds, device)
+    blob = _blob_hx(sd, head_sds, device, hx)
     x = synth.features(B, F, seed=9)
     if B > 3:
         x[3] = 0.0
@@ -833,12 +843,13 @@ def test_small_batch_path_is_bit_identical_to_the_fused_kernel(F, B, head_sds, d
     assert np.degrees(np.abs(b.cpu().numpy() - ref).max()) <= POSE_TOL_DEG
 
 
-def test_small_batch_path_landmarks_workspace_and_errors(head_sds, device):
+@pytest.mark.parametrize("hx", HX_MODES)
+def test_small_batch_path_landmarks_workspace_and_errors(hx, head_sds, device):
     """Raw-landmark entry of the small-batch path: same bits as the fused launch incl. the validity mask; garbage (NaN)
     in the workspace and in the dead faces of a partial tile does not leak; wrong blob mode / short workspace are refused."""
     from nlml_hpe_amd import _lib
     sd = synth.encoder_state_dict(1404, seed=0)
-    blob = _blob_hx(sd, head_sds, device)
+    blob = _blob_hx(sd, head_sds, device, hx)
     raw = synth.raw_landmarks(131, seed=17)
     raw[3] = np.array([0.25, 0.5, 0.75], np.float32)
     raw[64] = 0.0
@@ -856,12 +867,13 @@ def test_small_batch_path_landmarks_workspace_and_errors(head_sds, device):
         ops.landmarks_to_pose_small(rt, _blob(sd, head_sds, device), True)    # f32 blob: split-f16 only
 
 
-def test_model_dispatches_small_batches_and_graph_replays(head_sds, device):
+@pytest.mark.parametrize("hx", HX_MODES)
+def test_model_dispatches_small_batches_and_graph_replays(hx, head_sds, device):
     """HIPPoseModel in split-f16 mode uses the small-batch path up to SMALL_BATCH_MAX faces (same bits either way), and
     the five-launch sequence replays from a hipGraph."""
     from nlml_hpe_amd.model import HIPPoseModel
     sd = synth.encoder_state_dict(1404, seed=0)
-    model = HIPPoseModel(sd, head_sds, device=device)
+    model = HIPPoseModel(sd, head_sds, device=device, mode=hx)
     raw = torch.from_numpy(synth.raw_landmarks(300, seed=8)).to(device)
     assert model._small(300) and not model._small(model.SMALL_BATCH_MAX + 1)
     assert torch.equal(model.from_landmarks(raw), ops.landmarks_to_pose(raw, model.blob, True))
@@ -890,7 +902,7 @@ def test_empty_batches_are_no_ops_in_every_k2_path(head_sds, device):
     sd = synth.encoder_state_dict(1404, seed=0)
     x0 = torch.empty((0, 1404), dtype=torch.float32, device=device)
     r0 = torch.empty((0, 468, 3), dtype=torch.float32, device=device)
-    for mode in ("f32", "f16x2", "bf16"):
+    for mode in ("f32", "f16x2", "f16x2s", "bf16"):
         blob = torch.from_numpy(weights.pack_blob(sd, head_sds, _lib.mode_from_name(mode))).to(device)
         assert tuple(ops.encoder_heads_fwd(x0, blob, 1404).shape) == (0, 3)
         out, lat, val = ops.landmarks_to_pose(r0, blob, True, return_latent=True, return_valid=True)
@@ -910,7 +922,7 @@ def test_empty_batches_are_no_ops_in_every_k2_path(head_sds, device):
 FX3B_REF_VS_TRUTH_DEG = 8.3e-5
 
 
-@pytest.mark.parametrize("mode", ["f16x2", "f32"])
+@pytest.mark.parametrize("mode", ["f16x2", "f16x2s", "f32"])
 def test_fx3b_reference_range_golden(mode, head_sds, golden_dir, device):
     import fixture_models
     from nlml_hpe_amd import _lib
@@ -932,10 +944,10 @@ def test_fx3b_reference_range_golden(mode, head_sds, golden_dir, device):
     assert e_ref <= bound + FX3B_REF_VS_TRUTH_DEG, (mode, e_ref)
 
 
-FX3B_KERNEL_VS_TRUTH_DEG = {"f16x2": 1e-4, "f32": 1e-4}
+FX3B_KERNEL_VS_TRUTH_DEG = {"f16x2": 1e-4, "f16x2s": 1e-4, "f32": 1e-4}
 
 
-@pytest.mark.parametrize("mode", ["f16x2", "f32"])
+@pytest.mark.parametrize("mode", ["f16x2", "f16x2s", "f32"])
 def test_fx3c_no_worse_than_the_reference_itself(mode, head_sds, golden_dir, device):
     """Parity where the reference operates, stated as a statistic over 16,384 faces (FX3c = FX3b's model, poses over the trained
     bins): the kernel's distance from the f64 truth is NO WORSE THAN THE REFERENCE'S OWN in p50, p99 and max (5 % slack), and the
@@ -961,10 +973,18 @@ def test_fx3c_no_worse_than_the_reference_itself(mode, head_sds, golden_dir, dev
     # split-f16 kernel: 1.23-1.27x the reference's distance from the truth (measured; its layer-0 / layer-1 accumulators round
     # 264 / 192 times per dot product at full magnitude and there is no register room for block sums), 0.05 % of the faces
     # beyond 1e-4 deg of the truth, max 1.26e-4 deg.  Bounds = measured + 20 %, not looser.
-    ratio = {"f32": 1.05, "f16x2": 1.5}[mode]
+    # strict-fast kernel (f16x2s: the small products of each K step accumulate apart in layers 0 to 2): measured 1.49e-5 /
+    # 4.65e-5 / 9.2e-5 deg = 0.85-0.93x the reference's distance: held to the f32 kernel's bounds.
+    ratio = {"f32": 1.05, "f16x2s": 1.05, "f16x2": 1.5}[mode]
     for s_ in ("p50", "p99", "max"):
         assert k[s_] <= ratio * r[s_], (mode, s_, k, r)
-    if mode == "f32":
+    if mode == "f16x2s":
+        # nothing beyond 1e-4 deg of the truth.  Against the reference's batched output: two evaluations with INDEPENDENT errors of
+        # 1.5e-5 and 1.7e-5 deg p50 -- 0.073 % of the faces differ by more than 1e-4 deg, max 1.34e-4 deg (measured; bounds +20 %).
+        # (The reference against ITSELF, batched vs one-face calls: 0.012 %, 1.23e-4 deg -- its one-face results are 9e-6 deg p50 from the truth.)
+        assert k["max"] <= POSE_TOL_DEG and k["frac_above_1e-4"] == 0.0
+        assert vs_ref["max"] <= 1.6e-4 and vs_ref["frac_above_1e-4"] <= 9e-4, vs_ref
+    elif mode == "f32":
         assert k["max"] <= POSE_TOL_DEG and k["frac_above_1e-4"] == 0.0
         # against the reference's batched output (two f32 evaluations, each ~4e-5 deg from the truth in the tail): 0.012 % of the faces
         # differ by more than 1e-4 deg, max 1.20e-4 deg -- exactly what the reference shows against ITSELF (batched vs one-face calls:
@@ -975,7 +995,7 @@ def test_fx3c_no_worse_than_the_reference_itself(mode, head_sds, golden_dir, dev
         assert vs_ref["max"] <= 2.2e-4 and vs_ref["frac_above_1e-4"] <= 4.2e-3, vs_ref
 
 
-@pytest.mark.parametrize("mode", ["f16x2", "f32"])
+@pytest.mark.parametrize("mode", ["f16x2", "f16x2s", "f32"])
 def test_fx2b_heads_operating_points_golden(mode, head_sds, golden_dir, device):
     """The heads at their own inputs (rows of U_*, trained cosine curves to +-60 deg) through the fused forward, against what
     the reference's CombinedAnglePredictionModel returned on the same x and weights: the 1e-4 deg bar, both parity modes."""
@@ -989,7 +1009,7 @@ def test_fx2b_heads_operating_points_golden(mode, head_sds, golden_dir, device):
     _report(f"fx2b_{mode}", max_abs_deg=e, latent_abs=e_lat)
     assert e_lat <= 5e-7, e_lat
     assert e <= POSE_TOL_DEG, e
-    if mode == "f16x2":
+    if mode in HX_MODES:
         small = ops.encoder_heads_fwd_small(torch.from_numpy(x).to(device), blob, 136)
         assert torch.equal(small, out)
 
