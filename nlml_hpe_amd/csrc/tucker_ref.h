@@ -32,6 +32,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "tucker_common.h"
 
 namespace nlml {
@@ -78,6 +80,16 @@ __device__ __forceinline__ double uniform_f64(double v) {
 // Evaluations of machine slots (slots >> 4n) & 15, n < NE (f-vectors in sh.fvec[slot], parameters par(slot, k)) against the rows
 // xrow(slot); results into rs.err[slot] (and x_hat rows where xhrow(slot) != nullptr).  All 512 threads; barriers inside.
 // par / xrow / xhrow are small structs passed BY VALUE (a reference into the caller's frame would be scratch memory here).
+//
+// BALANCED passes (NE >= TR_BAL_FROM): with thread t on columns t and t + 768 the 22 wave-columns (1404 / 64) fall 6 / 6 / 5 / 5 on
+// the four SIMDs (waves w, w + 4, w + 8 share a SIMD: tools/probes/wave_simd_map_probe.hip), so two SIMDs issue 48 (wave-column,
+// evaluation) chains while the pass needs 44 per SIMD: 0.917 of the issue slots at best.  Here the unit of work is (wave-column,
+// half of the evaluations): SIMD class s = w & 3 takes wave-columns 5s .. 5s+4 whole -- two each for its first two waves, one for
+// the third -- and the third wave adds HALF of wave-column 20 + (s >> 1): evaluations [0, SP) for even s, [SP, NE) for odd s, SP = ceil(NE / 2).
+// Every SIMD then issues 5 NE + SP (or + NE - SP) chains, 44 of 44 at NE = 8.  Same chains per (column, evaluation): same bits.
+#ifndef TR_BAL_FROM
+#define TR_BAL_FROM 2
+#endif
 template <int NE, typename ParT, typename XRow, typename XhRow>
 __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh, TuckerRefShared& rs, const float* __restrict__ Wm_,
                                                           const ParT par, const unsigned slots, const XRow xrow,
@@ -105,13 +117,24 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)Wm_ >> 32)) << 32) |
       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)Wm_));
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wm, 0, TQ * TM * 4, 0x00027000);
+  constexpr bool BAL = NE >= TR_BAL_FROM && TR_NT == 768 && TR_COLS == 2;
   unsigned mc[TR_COLS];
   bool livec[TR_COLS];
+  int var = 0;                    // wave-uniform: 0 = both columns take every evaluation; 1 / 2 = column 1 takes [0, SP) / [SP, NE) only
+  if constexpr (BAL) {
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), s4 = w & 3, r = w >> 2;
+    const int wc0 = 5 * s4 + 2 * r, wc1 = r < 2 ? wc0 + 1 : 20 + (s4 >> 1);
+    mc[0] = wc0 * 64 + (tid & 63);
+    mc[1] = wc1 * 64 + (tid & 63);
+    var = r < 2 ? 0 : 1 + (s4 & 1);
+  } else {
 #pragma unroll
-  for (int c = 0; c < TR_COLS; ++c) {
-    mc[c] = tid + TR_NT * c;
-    livec[c] = mc[c] < (unsigned)TM;
+    for (int c = 0; c < TR_COLS; ++c) mc[c] = tid + TR_NT * c;
   }
+#pragma unroll
+  for (int c = 0; c < TR_COLS; ++c) livec[c] = mc[c] < (unsigned)TM;
+  constexpr int SP = (NE + 1) / 2;   // where the split wave-column's evaluations divide
+  const int c1_lo = var == 2 ? SP : 0, c1_hi = var == 1 ? SP : NE;   // column 1's evaluations
   // Wm ring: block b = (i*3 + j)*3 + k holds rows 3b .. 3b+2 and lives in slot k; the loads of block b + 2 are issued before the
   // arithmetic of block b.  (Measured: a five- or nine-slot ring is no faster -- the L2 latency is covered; re-reading u and f_y
   // from LDS with every block is 7 % slower; holding f_p for all three k in registers spills at the 168 registers that three
@@ -166,7 +189,10 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
 #endif
   TRS(1);
 
-  // (i, j, k, l) in the einsum's nesting order
+  // (i, j, k, l) in the einsum's nesting order.  VAR (compile time inside, chosen per wave): which evaluations column 1 takes
+  auto main_loop = [&](auto var_c) {
+  constexpr int VAR = decltype(var_c)::value;
+  auto takes = [](int c, int n) { return c == 0 || VAR == 0 || (VAR == 1 ? n < SP : n >= SP); };
 #pragma unroll 1
   for (int i = 0; i < 5; ++i) {
     double u[NE];
@@ -206,36 +232,44 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
             for (int g = 0; g < TR_ILV; ++g)
 #pragma unroll
               for (int c = 0; c < TR_COLS; ++c)
-                if (n0 + g < NE) t[g][c] = wd[c] * u[n0 + g];
+                if (n0 + g < NE && takes(c, n0 + g)) t[g][c] = wd[c] * u[n0 + g];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < TR_ILV; ++g)
 #pragma unroll
               for (int c = 0; c < TR_COLS; ++c)
-                if (n0 + g < NE) t[g][c] = t[g][c] * fy[n0 + g];
+                if (n0 + g < NE && takes(c, n0 + g)) t[g][c] = t[g][c] * fy[n0 + g];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < TR_ILV; ++g)
 #pragma unroll
               for (int c = 0; c < TR_COLS; ++c)
-                if (n0 + g < NE) t[g][c] = t[g][c] * fp[n0 + g];
+                if (n0 + g < NE && takes(c, n0 + g)) t[g][c] = t[g][c] * fp[n0 + g];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < TR_ILV; ++g)
 #pragma unroll
               for (int c = 0; c < TR_COLS; ++c)
-                if (n0 + g < NE) t[g][c] = t[g][c] * fr[l][n0 + g];
+                if (n0 + g < NE && takes(c, n0 + g)) t[g][c] = t[g][c] * fr[l][n0 + g];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < TR_ILV; ++g)
 #pragma unroll
               for (int c = 0; c < TR_COLS; ++c)
-                if (n0 + g < NE) acc[c][n0 + g] = t[g][c] + acc[c][n0 + g];
+                if (n0 + g < NE && takes(c, n0 + g)) acc[c][n0 + g] = t[g][c] + acc[c][n0 + g];
             __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
     }
+  }
+  };
+  if constexpr (BAL) {
+    if (var == 0) main_loop(std::integral_constant<int, 0>{});
+    else if (var == 1) main_loop(std::integral_constant<int, 1>{});
+    else main_loop(std::integral_constant<int, 2>{});
+  } else {
+    main_loop(std::integral_constant<int, 0>{});
   }
   TRS(2);
   // residuals squared -> LDS (and x_hat out)
@@ -250,7 +284,7 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
 #endif
 #pragma unroll
     for (int c = 0; c < TR_COLS; ++c)
-      if (livec[c]) {
+      if (livec[c] && (c == 0 || (n >= c1_lo && n < c1_hi))) {
         const double d = (double)gload<float>(xr + mc[c]) - acc[c][n];
         rl->d2[n][mc[c]] = d * d;
         if (xh) xh[mc[c]] = acc[c][n];
