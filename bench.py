@@ -643,7 +643,7 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
                      "frac": evs * TUCKER_REF_OPS_PER_EVAL / 1e12 / PEAK_F64_VALU_TOPS,
                      "frac_in_algorithmic_flop_of_f64_peak": evs * TUCKER_FLOP_PER_EVAL / 1e12 / PEAK_F64_TFLOPS, "traffic": None,
                      "kernel": "tucker_objective_ref_kernel", "kernel_ms": ms,
-                     "note": "5 separately rounded f64 operations per (q, m) on the vector ALUs; 1404 of 1536 lane slots live (0.914); "
+                     "note": "5 separately rounded f64 operations per (q, m) on the vector ALUs; balanced passes: every SIMD issues the same number of (column, evaluation) chains; "
                              "sustained rate (400 warm-up launches, 200 timed back to back); a burst after idle runs at ~2.0 GHz (tools/td_ref_stamps.py)"}}
     return ex
 

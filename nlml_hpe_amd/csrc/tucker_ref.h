@@ -15,12 +15,13 @@
 // matrix path.  The bound is the f64 vector issue rate (16 lanes per clock and SIMD: 39.3 T operations/s at 2.4 GHz, i.e.
 // 41.5 M evaluations/s); oracle: oracle/csrc/oracle.c oracle_tucker_objective_reforder, pinned to FX4 bit for bit.
 //
-// One workgroup of 768 threads = 12 waves, three per SIMD; thread t owns columns t and t+768 (1404 of the 1536 lane slots are live:
-// 0.914 -- 22 wave-columns do not divide over 4 SIMDs); NE = 1..8 evaluations share every Wm load.  Three waves per SIMD because the
+// One workgroup of 768 threads = 12 waves, three per SIMD; NE = 1..8 evaluations share every Wm load.  A one-evaluation pass puts thread t
+// on columns t and t+768 (1404 of the 1536 lane slots live); passes of 2..8 evaluations deal (wave-column, half of the evaluations)
+// units so that every SIMD issues the same number of chains (see "BALANCED passes" at tucker_ref_pass).  Three waves per SIMD because the
 // waves of a SIMD do not advance together: the oldest takes every issue slot it can use, its siblings finish one after the other, and
 // the last one runs alone -- at the 4.8 cycles per instruction ONE wave sustains -- for 1/3 of the pass (1/2 with two waves).
 // What keeps the vector ALUs fed (round 3; the round-2 form -- 512 threads x 3 columns -- ran at 0.46 of the issue rate, this one
-// at 0.58: DESIGN.md section 3 has the stamps and what bounds it now):
+// at 0.58 in a burst / 0.69 sustained, 0.63 / 0.74 with the balanced passes: DESIGN.md section 3 has the stamps and what bounds it now):
 //   * Wm rows come through a three-slot register ring, the loads of block (i,j,k)+2 issued before the arithmetic of block
 //     (i,j,k) (buffer loads: scalar row offset + the lane's column offset, no address arithmetic on the vector ALUs).  Round 2
 //     loaded the nine values of a block at its top and used them at once: 45 exposed L2 round trips per pass;
@@ -50,6 +51,25 @@ constexpr int TR_LEAVES = 16;              // numpy pairwise tree for n = 1404 (
 #endif
 constexpr int TR_ILV = TR_ILV_N;           // evaluations whose operation chains advance together (x 2 columns)
 constexpr int TR_NFAC = 14;                // u[5], f_y[3], f_p[3], f_r[3] of one evaluation
+
+// the (column, evaluation) pairs of a main-loop variant, evaluation-major (tucker_ref_pass has the variants)
+template <int NE, int VAR>
+struct TrPairs {
+  int cnt;
+  int c[2 * NE], n[2 * NE];
+  constexpr TrPairs() : cnt(0), c{}, n{} {
+    constexpr int SP = (NE + 1) / 2;
+    for (int nn = 0; nn < NE; ++nn)
+      for (int cc = 0; cc < 2; ++cc) {
+        const bool on = cc == 0 || VAR == 0 || (VAR == 1 ? nn < SP : nn >= SP);
+        if (on) {
+          c[cnt] = cc;
+          n[cnt] = nn;
+          ++cnt;
+        }
+      }
+  }
+};
 
 struct TuckerRefShared {
   double d2[TR_MAXE][TM + 4];              // squared residuals of the pass's evaluations
@@ -192,7 +212,8 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
   // (i, j, k, l) in the einsum's nesting order.  VAR (compile time inside, chosen per wave): which evaluations column 1 takes
   auto main_loop = [&](auto var_c) {
   constexpr int VAR = decltype(var_c)::value;
-  auto takes = [](int c, int n) { return c == 0 || VAR == 0 || (VAR == 1 ? n < SP : n >= SP); };
+  constexpr TrPairs<NE, VAR> PR{};
+  constexpr int CNT = PR.cnt, NG = (CNT + 2 * TR_ILV - 1) / (2 * TR_ILV), G = (CNT + NG - 1) / NG;
 #pragma unroll 1
   for (int i = 0; i < 5; ++i) {
     double u[NE];
@@ -222,41 +243,31 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
           double wd[TR_COLS];
 #pragma unroll
           for (int c = 0; c < TR_COLS; ++c) wd[c] = (double)wr[k][l][c];
-          // the five operations of a (column, evaluation) pair depend on each other; TR_ILV evaluations x 2 columns advance
-          // together, one operation each per stage (stages pinned by sched_barrier: left alone, hipcc runs the chains one after
-          // the other through a single temporary)
+          // the five operations of a (column, evaluation) pair depend on each other; the sweep's pairs advance together in groups of
+          // up to 2 * TR_ILV chains of equal size (16 pairs: 8 + 8, 12: 6 + 6), one operation each per stage (stages pinned by
+          // sched_barrier: left alone, hipcc runs the chains one after the other through a single temporary)
 #pragma unroll
-          for (int n0 = 0; n0 < NE; n0 += TR_ILV) {
-            double t[TR_ILV][TR_COLS];
+          for (int g0 = 0; g0 < NG; ++g0) {
+            double t[G];
 #pragma unroll
-            for (int g = 0; g < TR_ILV; ++g)
-#pragma unroll
-              for (int c = 0; c < TR_COLS; ++c)
-                if (n0 + g < NE && takes(c, n0 + g)) t[g][c] = wd[c] * u[n0 + g];
+            for (int q = 0; q < G; ++q)
+              if (g0 * G + q < CNT) t[q] = wd[PR.c[g0 * G + q]] * u[PR.n[g0 * G + q]];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < TR_ILV; ++g)
-#pragma unroll
-              for (int c = 0; c < TR_COLS; ++c)
-                if (n0 + g < NE && takes(c, n0 + g)) t[g][c] = t[g][c] * fy[n0 + g];
+            for (int q = 0; q < G; ++q)
+              if (g0 * G + q < CNT) t[q] = t[q] * fy[PR.n[g0 * G + q]];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < TR_ILV; ++g)
-#pragma unroll
-              for (int c = 0; c < TR_COLS; ++c)
-                if (n0 + g < NE && takes(c, n0 + g)) t[g][c] = t[g][c] * fp[n0 + g];
+            for (int q = 0; q < G; ++q)
+              if (g0 * G + q < CNT) t[q] = t[q] * fp[PR.n[g0 * G + q]];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < TR_ILV; ++g)
-#pragma unroll
-              for (int c = 0; c < TR_COLS; ++c)
-                if (n0 + g < NE && takes(c, n0 + g)) t[g][c] = t[g][c] * fr[l][n0 + g];
+            for (int q = 0; q < G; ++q)
+              if (g0 * G + q < CNT) t[q] = t[q] * fr[l][PR.n[g0 * G + q]];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < TR_ILV; ++g)
-#pragma unroll
-              for (int c = 0; c < TR_COLS; ++c)
-                if (n0 + g < NE && takes(c, n0 + g)) acc[c][n0 + g] = t[g][c] + acc[c][n0 + g];
+            for (int q = 0; q < G; ++q)
+              if (g0 * G + q < CNT) acc[PR.c[g0 * G + q]][PR.n[g0 * G + q]] = t[q] + acc[PR.c[g0 * G + q]][PR.n[g0 * G + q]];
             __builtin_amdgcn_sched_barrier(0);
           }
         }
