@@ -84,6 +84,22 @@ void run_shift(const float* buf, uint32_t bytes, float* out, uint32_t shift) {
   printf("start shifted by %7u B per workgroup, depth %2d: %7.3f ms  %6.1f GB/s per CU = %5.1f B/clk at 2.4 GHz\n", shift, DEPTH, ms, bps / 1e9, bps / 2.4e9);
 }
 
+// GRID sweep: the same stream with fewer workgroups (= fewer CUs streaming at once): is the ceiling the CU's intake or the L2's output?
+template <int DEPTH>
+void run_grid(const float* buf, uint32_t bytes, float* out, int grid) {
+  const int reps = 8;
+  stream<0, DEPTH><<<grid, 256>>>(buf, bytes, 2, out);
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0);
+  stream<0, DEPTH><<<grid, 256>>>(buf, bytes, reps, out);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double bps = (double)bytes * reps / (ms * 1e-3);
+  printf("%3d workgroups (one per CU), depth %2d: %7.3f ms  %6.1f GB/s per CU = %5.1f B/clk at 2.4 GHz; all together %6.2f TB/s\n", grid, DEPTH, ms,
+         bps / 1e9, bps / 2.4e9, bps * grid / 1e12);
+}
+
 int main() {
   const uint32_t bytes = 9600 * 1024;
   float *buf, *out;
@@ -97,5 +113,7 @@ int main() {
   run<2, 8>(buf, bytes, out, "nt");
   run<18, 8>(buf, bytes, out, "sc1 nt");
   for (uint32_t shift : {0u, 4096u, 36864u, 299008u, 1200128u}) run_shift<16>(buf, bytes, out, shift);
+  for (int grid : {1, 8, 16, 32, 64, 128, 192, 256}) run_grid<16>(buf, bytes, out, grid);
+  for (int grid : {8, 256}) run_grid<32>(buf, bytes, out, grid);
   return 0;
 }
