@@ -1083,7 +1083,7 @@ def test_video_entry_point_shards_streams_over_ranks(repo_root, device, tmp_path
         assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("mode", ["f16x2", "f32"])
+@pytest.mark.parametrize("mode", ["f16x2", "f16x2s", "f32"])
 def test_batch_beyond_2_31_elements_is_indexed_in_64_bits(mode, head_sds, device):
     """3,100,000 faces = 4.35e9 input elements (17 GB): every row offset in K1/K2 has to be 64-bit.  A face's result does not
     depend on its position in the batch, so windows of the big batch (first tile, around the 2^31- and 2^32-element marks, a
@@ -1093,7 +1093,7 @@ def test_batch_beyond_2_31_elements_is_indexed_in_64_bits(mode, head_sds, device
     if free < 80 * 2**30:
         pytest.skip("needs ~60 GB of device memory")
     sd = synth.encoder_state_dict(1404, seed=0)
-    blob = (_blob_hx if mode == "f16x2" else _blob)(sd, head_sds, device)
+    blob = _blob_hx(sd, head_sds, device, mode) if mode in HX_MODES else _blob(sd, head_sds, device)
     base = synth.raw_landmarks(4096, seed=21)
     base[::97] = 0.0                                                   # "no face" rows (generatePose_on_video.py:118)
     base = torch.from_numpy(base).to(device)
@@ -1114,7 +1114,7 @@ def test_batch_beyond_2_31_elements_is_indexed_in_64_bits(mode, head_sds, device
         a, b = pose[lo:hi].contiguous(), p2
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (mode, lo, hi, float((a - b).abs().max()))
     assert bool(torch.isfinite(pose[valid]).all())
-    if mode == "f16x2":     # K1 alone and K2 from features at the same size: the two-launch path leaves the fused launch's bits
+    if mode in HX_MODES:    # K1 alone and K2 from features at the same size: the two-launch path leaves the fused launch's bits
         feats = ops.normalize_ipd(raw, True)
         for lo, hi in ((mark - 100, mark + 100), (2 * mark - 70, 2 * mark + 61), (B - 37, B)):
             assert torch.equal(feats[lo:hi], ops.normalize_ipd(raw[lo:hi].contiguous(), True)), (lo, hi)
@@ -1302,13 +1302,14 @@ def test_reference_order_objective_on_200k_random_evaluations(tucker_art, device
     assert bad <= 1, bad      # (0 measured; 1 allowed for a cos value where libm is not correctly rounded AND the f32 rounding flips)
 
 
-def test_bench_line_carries_the_contract_fields(repo_root, device):
+@pytest.mark.parametrize("mode", ["f16x2", "f16x2s"])
+def test_bench_line_carries_the_contract_fields(mode, repo_root, device):
     """`python bench.py` (short run): ONE JSON line with the contract's fields, a roofline block, the CPU baseline with both live parity
     checks -- the seed-0 sample of the timed batch and the operating-range statistics (FX3c) next to the reference's own."""
     import subprocess
     import sys
     res = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--steps", "3", "--warmup", "1", "--settle-ms", "0",
-                          "--no-extra", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=repo_root)
+                          "--no-extra", "--cpu-seconds", "1", "--mode", mode], capture_output=True, text=True, timeout=600, cwd=repo_root)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -1324,7 +1325,11 @@ def test_bench_line_carries_the_contract_fields(repo_root, device):
     assert cb["parity_check"]["max_abs_deg_vs_f64_oracle"] <= POSE_TOL_DEG
     rng = cb["parity_check_operating_range"]
     k_, r_ = rng["kernel_vs_f64_truth"], rng["reference_batched_vs_f64_truth"]
-    assert rng["faces"] == 16384 and k_["p50_deg"] <= 1.5 * r_["p50_deg"] and k_["max_deg"] <= 1.5e-4
+    assert rng["faces"] == 16384 and rng["mode"] == mode and rec["config"]["mode"] == mode
+    if mode == "f16x2s":    # the strict-fast mode: inside the reference's own distance from the truth
+        assert k_["p50_deg"] <= 1.05 * r_["p50_deg"] and k_["max_deg"] <= POSE_TOL_DEG and k_["frac_above_1e-4_deg"] == 0.0
+    else:
+        assert k_["p50_deg"] <= 1.5 * r_["p50_deg"] and k_["max_deg"] <= 1.5e-4
 
 
 def test_bench_two_rank_path_on_one_gpu(repo_root, device):
