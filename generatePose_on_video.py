@@ -107,8 +107,8 @@ if __name__ == "__main__":
     parser.add_argument("--save_output", type=lambda s: str(s).lower() in ("1", "true", "yes", "tr"), required=True)
     parser.add_argument("--output_path", type=str)
     parser.add_argument("--device", default="cuda:0")
-    parser.add_argument("--mode", choices=["f16x2", "f32", "bf16"], default=None,
-                        help="kernel mode (default: NLML_HPE_MODE or f16x2 = fast; f32 = strict parity; bf16 = throughput only)")
+    parser.add_argument("--mode", choices=["f16x2", "f16x2s", "f32", "bf16"], default=None,
+                        help="kernel mode (default: NLML_HPE_MODE or f16x2 = fast; f16x2s = strict-fast; f32 = strict parity; bf16 = throughput only)")
     args = parser.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world > 1:                                             # one rank per GPU; RCCL ("nccl") unless rehearsing on one GPU

@@ -1,4 +1,5 @@
-// encoder_heads_f16x2.hip -- K2 in SPLIT-F16 PARITY mode (NLML_MODE_F16X2).
+// encoder_heads_f16x2.hip -- K2 on the f16 matrix cores: the split-f16 mode (NLML_MODE_F16X2, the fast default) and the strict-fast mode
+// (NLML_MODE_F16X2S: the same operands and instructions with split accumulators, template parameter SPLIT; see the kernel's comment).
 //
 // Same network, stages and jobs as the f32 parity kernel (encoder_heads.hip; reference:
 // NLML_HPE_Model_Builder.py:33-53,76-92,115-126) and the same <=1e-4 degree bar, but the contraction runs on
@@ -18,8 +19,9 @@
 // so there is no input-range limit.  f16 subnormal pieces are kept by the MFMA (tools/probes/mfma_f16_probe.hip), so small
 // values lose nothing beyond an absolute 2^-25.
 //
-// Structure: 64-face tiles, 4 waves; layer 0 in two passes of 512 neurons interleaved with the two K halves
-// of layer 1 (as in the f32 kernel: the 1024-wide layer-0 output of 64 faces is 256 KB in hi+lo f16);
+// Structure: 64-face tiles, 4 waves; layer 0's 1024-wide output of 64 faces is 256 KB in hi+lo f16, so it reaches layer 1 in two
+// halves of 512 neurons, each followed by one K half of layer 1 (NLML_MODE_F16X2: ONE pass over x on 256 accumulators per lane, the
+// second half waiting in registers; NLML_MODE_F16X2S: two passes over x of 128 + 128 accumulators, layer 1's parked in LDS meanwhile);
 // x is staged f32 -> (optional f64 IPD normalisation) -> hi/lo f16 through three rotating 32-column LDS slabs; every K step
 // issues ONE MFMA per slot with the step's fetches and the staging pieces spread behind them (step_fine); a stage's global
 // fetches ride in the previous stage's epilogue; the heads run one at a time over both face blocks (encoder_heads_f16x2_dev.h).
