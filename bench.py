@@ -11,7 +11,7 @@ One STEP = one pass of the hot path over one batch that is already resident in H
 raw landmarks f32[B,468,3] -> IPD normalisation -> encoder -> 3 heads -> (yaw,pitch,roll) f32[B,3],
 one fused HIP launch per rank (nlml_landmarks_to_pose), B = 65,536 faces per GPU (weak scaling),
 F = 1404 (the reference's real feature width).  --mode picks the kernel: f16x2 (default: split-f16 operands on the
-f16 matrix cores, f32 accumulate; ~1e-5 deg from the reference on small poses, 1.23x the reference's own distance from the exact
+f16 matrix cores, f32 accumulate; ~1e-5 deg from the reference on small poses, 1.10x the reference's own distance from the exact
 result at +-45 deg poses) or f32 (f32 matrix cores with blocked sums: the strict parity mode, 1/3 of the rate).  With N > 1 every
 step also all-gathers the [B,3] poses of all ranks over RCCL (the only collective the path has),
 on the communication stream, overlapped with the next step's compute; a second timed region of K steps without

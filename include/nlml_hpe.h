@@ -75,8 +75,8 @@ int nlml_normalize_ipd(const float* raw, int64_t B, int normalize,
  *       ~5x the faces/s; its error is ~0.1 deg max / 0.02 deg mean and is never claimed as parity);
  *       NLML_MODE_F16X2 = split-f16 parity mode: every f32 weight and activation is carried as two f16
  *       pieces (hi + lo, 22 significand bits) and a product runs as three f16 MFMAs with f32 accumulation.
- *       ~1e-5 deg from the reference on small poses; at the reference's operating range (FX3c) 2.1e-5 / 6.7e-5 / 1.26e-4 deg
- *       from the exact result in p50 / p99 / max = 1.23-1.27x the reference's own distance, 0.05 % of the faces beyond 1e-4
+ *       ~1e-5 deg from the reference on small poses; at the reference's operating range (FX3c) 1.86e-5 / 5.9e-5 / 1.22e-4 deg
+ *       from the exact result in p50 / p99 / max = 1.10 / 1.08 / 1.24x the reference's own distance, 0.024 % of the faces beyond 1e-4
  *       deg; ~3x NLML_MODE_F32's faces/s (the bench default).  No input-range limit: a
  *       face whose activations leave f16's range (|v| >= 65520 -- e.g. the reference's ipd == 0 -> 1e-6 branch,
  *       FeatureExtractor.py:47-48) is re-evaluated inside the same launch in f32 on the vector ALUs from the same
@@ -90,7 +90,8 @@ int nlml_normalize_ipd(const float* raw, int64_t B, int normalize,
  *       NLML_MODE_F16X2S = the same operands and the same three MFMAs per product, but the two SMALL products of a K step
  *       (w_lo*x_hi, w_hi*x_lo) accumulate in registers of their own in layers 0 to 2 and join the big sum once per K
  *       block: the matrix instruction truncates its products to the running sum's exponent, which is what costs
- *       NLML_MODE_F16X2 its 1.23x (profiles/r03_mfma_f16_numerics_probe.txt).  Strict parity at matrix-core speed: on FX3c
+ *       NLML_MODE_F16X2 its distance (profiles/r03_mfma_f16_numerics_probe.txt; that mode has room for the second accumulator set only from
+ *       layer 1's second K half on).  Strict parity at matrix-core speed: on FX3c
  *       no farther from the exact result than the reference itself, at ~0.78x NLML_MODE_F16X2's faces/s (layer 0 runs in
  *       two passes over x to make room for the second accumulator set).  Same packed image as NLML_MODE_F16X2 (+256
  *       bytes, so the size still names the mode), same range behaviour and slow path.

@@ -257,7 +257,7 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const Args& a, int64_t ro
 // this wave computes the 128 neurons of job 4 * pass + wave (4 blocks) for both face blocks, with SPLIT ACCUMULATORS (step_fine):
 // `acc` takes w_hi*x_hi, `accS` the two small products -- 256 accumulator registers per lane, the whole AGPR file, which is why
 // layer 0 runs in two passes of 512 neurons again (round 2 ran both halves in one pass on 256 single accumulators: x staged once
-// instead of twice, +3 % faces/s, but 1.23x the reference's distance from the exact result at the reference's operating range;
+// instead of twice, +3 % faces/s, but 1.10x (1.23x before layer 1's second half and layer 2 got split accumulators) the reference's distance from the exact result at the reference's operating range;
 // this form is 12 % inside it) and why layer 1's accumulators are parked in LDS meanwhile (the caller).
 template <bool VEC4, bool NORM>
 __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64_t row0, int tid, int pass,
@@ -453,7 +453,8 @@ __device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64
 }
 
 // ------------------------------------------------------------------------------------------
-// SPLIT = false: NLML_MODE_F16X2, layer 0 in one pass over x on single accumulators (the fast mode);
+// SPLIT = false: NLML_MODE_F16X2, layer 0 in one pass over x on single accumulators, so are layer 1's first K half (no register
+//                is free while layer 0's second half waits); split accumulators from layer 1's second K half on (the fast mode);
 // SPLIT = true:  NLML_MODE_F16X2S, split accumulators (step_fine), layer 0 in two passes (the strict-fast mode).
 template <bool VEC4, bool NORM, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
@@ -512,7 +513,13 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
     }
     __syncthreads();
     HXS(5);
-    kloop<4, 2, 32>(acc1, acc1, w1 + (size_t)32 * (4 * 2 * 64), c.lds + O_H1H + (c.f * S_H1H + 8 * c.h) * 2, P_H1H, 32 * S_H1H * 2);
+    {  // layer 0's second half is stored: 128 registers are free, and layer 1's second K half runs with the small products of each
+       // step in accumulators of their own (see step_fine; FX3c p50 2.08e-5 -> 1.86e-5 deg together with layer 2's, at no cost)
+      f32x16 acc1s[4][2];
+      zero_acc<4, 2>(acc1s);
+      kloop<4, 2, 32>(acc1, acc1s, w1 + (size_t)32 * (4 * 2 * 64), c.lds + O_H1H + (c.f * S_H1H + 8 * c.h) * 2, P_H1H, 32 * S_H1H * 2);
+      add_acc<4, 2>(acc1, acc1s);
+    }
     HXS(6);
     __syncthreads();     // H1H is free again: for H2
     HXS(7);
@@ -590,8 +597,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
   f32x16 acc3[1][2];
   h8 wr3[ring_slots(1, 2)][1][2];
   // E2: 512 -> 256, ReLU; h3 overwrites h2 => barrier between the K loop and the store
-  if constexpr (SPLIT) job_run_split<2, 2, ST_E2>(c, wv, acc2, wr2, O_H2, P_H2, S_H2, 0, 0);
-  else job_run<2, 2, ST_E2>(c, wv, acc2, wr2, O_H2, P_H2, S_H2, 0, 0);
+  job_run_split<2, 2, ST_E2>(c, wv, acc2, wr2, O_H2, P_H2, S_H2, 0, 0);   // (both modes: split accumulators)
   __syncthreads();
   job_store<2, 2, ACT_RELU>(c, acc2, O_H3, P_H3, S_H3, 64 * wv, 0, c.hdr.inv_scale[ST_E2],
                             fetch_hook<8, 1, 2, ST_E3>(c, wv, acc3, wr3));

@@ -113,7 +113,7 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[NB][NFB], const h8 (&w)[N
 // accS to acc once at the end (layer 1: also at its K midpoint).  v_mfma_f32_32x32x16_f16 aligns C and its 16 products to the
 // largest exponent among them with ~3 guard bits and truncates each aligned addend (tools/probes/mfma_f16_numerics_probe.hip):
 // against a large running sum one instruction costs 0.41 ulp rms of the sum.  With all three products in one accumulator that is
-// 3 x 88 such costs per layer-0 dot product, and the kernel sat 1.23x further from the exact result than the reference's own f32
+// 3 x 88 such costs per layer-0 dot product, and the kernel with single accumulators throughout sat 1.23x further from the exact result than the reference's own f32
 // GEMM at the reference's operating range (FX3c).  Now the big accumulator takes ONE instruction per 16 k, the small one sums
 // values 2^-11 the size (its truncations are 2^-11 the size too): measured p50 2.08e-5 -> 1.49e-5 deg, 12 % INSIDE the reference's
 // distance in p50, p99 and max.  Pass the same array twice for a single accumulator (the tail layers E3.. and the heads).

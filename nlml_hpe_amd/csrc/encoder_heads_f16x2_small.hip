@@ -18,6 +18,8 @@
 //   64*tile + 32*fb + (lane&31).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/nlml_hpe.h"
 #include "abi_internal.h"
 #include "encoder_heads_f16x2_dev.h"
@@ -104,16 +106,18 @@ struct LayerArgs {
   h8* xout;
   int64_t B;
   int stage, K16, nb_stage, jobs, ntiles, buf_steps, act;
-  int fold_step;      // K step after which the small accumulator is folded into the big one mid-way (layer 1: 32; else 0)
+  int fold_step;      // K step after which the small accumulator is folded into the big one mid-way (layer 1 in NLML_MODE_F16X2S: 32; else 0)
+  int split_from;     // first K step whose small products go to the small accumulator (SPLIT kernels; layer 1 in NLML_MODE_F16X2: 32)
   int in_step0[12];   // first input K step of job j (its input column / 16)
   int out_col0[12];   // first output column of job j
 };
 
 // R = depth of the operand ring.  With few units (one wave per CU) a unit's rate is its own loads in flight, so those
 // launches use 64-thread workgroups (the units spread over the CUs instead of sharing one four at a time) and R = 8.
-// SPLIT: NLML_MODE_F16X2S, the small products of a K step accumulate apart (as the fused kernel's step_fine does in that mode).
-template <int NBW, int R, bool SPLIT>
+// SPLITK != 0: the small products of a K step accumulate apart, as the fused kernel's step_fine does for this layer in the blob's mode.
+template <int NBW, int R, int SPLITK>
 __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
+  constexpr bool SPLIT = SPLITK != 0;   // SPLITK: 0 = single accumulators, 1 = split accumulators, 2 = split from K step a.split_from on
   const int lane = threadIdx.x & 63, f = lane & 31, h = lane >> 5;
   const int groups = a.nb_stage / NBW;                     // units per (tile, job)
   const int64_t u = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -179,7 +183,9 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
         }
       }
   };
-  auto mma = [&](int slot) {
+  const int split_from = a.split_from;
+  auto mma3 = [&](int slot, auto split_c) {
+    constexpr bool SP = decltype(split_c)::value;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       const int wp_ = t == 0 ? 1 : 0, xp_ = t == 1 ? 1 : 0;   // (lo,hi), (hi,lo), (hi,hi): the fused kernel's order
@@ -188,29 +194,54 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
 #pragma unroll
         for (int fb = 0; fb < 2; ++fb)
           // split accumulators, exactly as the fused kernel (encoder_heads_f16x2_dev.h step_fine): small products apart
-          if (SPLIT && t < 2) accS[SPLIT ? i : 0][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[slot][i][wp_], xr[slot][fb][xp_], accS[SPLIT ? i : 0][fb], 0, 0, 0);
+          if (SP && t < 2) accS[SP ? i : 0][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[slot][i][wp_], xr[slot][fb][xp_], accS[SP ? i : 0][fb], 0, 0, 0);
           else acc[i][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[slot][i][wp_], xr[slot][fb][xp_], acc[i][fb], 0, 0, 0);
+    }
+  };
+  // K steps below split_from (wave-uniform) run on the single accumulator, as the fused kernel's does where it has no register for
+  // a second set (NLML_MODE_F16X2: layer 1's first K half)
+  auto mma = [&](int slot, int step) {
+    if constexpr (SPLITK == 2) {
+      if (step >= split_from) mma3(slot, std::true_type{});
+      else mma3(slot, std::false_type{});
+    } else if constexpr (SPLITK == 1) {
+      mma3(slot, std::true_type{});
+    } else {
+      mma3(slot, std::false_type{});
     }
   };
 #pragma unroll
   for (int d = 0; d < D; ++d) load(d, d < K16 ? d : K16 - 1);
   const int groups4 = K16 / R;
-  for (int g = 0; g < groups4; ++g) {
+  // groups [g0, g1) of R steps; sp_c: which accumulators the groups' small products go to (SPLITK == 2: the launcher makes
+  // split_from a multiple of R, so the choice is per group and the loop body has no branch)
+  auto run_groups = [&](int g0, int g1, auto sp_c) {
+    for (int g = g0; g < g1; ++g) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int sp = g * R + r + D;
-      load((r + D) % R, sp < K16 ? sp : K16 - 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(r);
-      __builtin_amdgcn_sched_barrier(0);
-      if (SPLIT && g * R + r + 1 == a.fold_step) fold(true);   // (fold_step 0: never)
+      for (int r = 0; r < R; ++r) {
+        const int sp = g * R + r + D;
+        load((r + D) % R, sp < K16 ? sp : K16 - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma3(r, sp_c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (SPLIT && g * R + r + 1 == a.fold_step) fold(true);   // (fold_step 0: never)
+      }
     }
+  };
+  if constexpr (SPLITK == 2) {
+    const int gs = split_from / R < groups4 ? split_from / R : groups4;
+    run_groups(0, gs, std::false_type{});
+    run_groups(gs, groups4, std::true_type{});
+  } else if constexpr (SPLITK == 1) {
+    run_groups(0, groups4, std::true_type{});
+  } else {
+    run_groups(0, groups4, std::false_type{});
   }
   const int tail = K16 - groups4 * R;   // steps groups4*R + r sit in slot r (loaded D steps earlier, or by the prologue)
 #pragma unroll
   for (int r = 0; r < R - 1; ++r)
     if (r < tail) {
-      mma(r);
+      mma(r, groups4 * R + r);
       if (SPLIT && groups4 * R + r + 1 == a.fold_step) fold(true);
     }
 
@@ -311,19 +342,26 @@ int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* r
     LayerArgs a{};
     a.blob = blob; a.xin = in; a.xout = outb; a.B = B; a.stage = stages[s].stage; a.K16 = stages[s].K16;
     a.nb_stage = stages[s].nb; a.jobs = stages[s].jobs; a.ntiles = ntiles; a.buf_steps = buf_steps; a.act = hx::ACT_RELU;
-    a.fold_step = (split && stages[s].stage == ST_E1) ? 32 : 0;   // the fused kernel adds layer 1's small products at its K midpoint too
+    // which K steps run on split accumulators, exactly as the fused kernel of the blob's mode (encoder_heads_f16x2.hip):
+    //   NLML_MODE_F16X2S: all of layers 0, 1, 2, layer 1's small sums added at its K midpoint as well as at its end;
+    //   NLML_MODE_F16X2:  layer 1 from its K midpoint on, layer 2; layer 0 never (kernel without the second set)
+    const bool e0 = stages[s].stage == ST_E0, e1 = stages[s].stage == ST_E1;
+    const bool use_split = split || !e0;
+    a.fold_step = (split && e1) ? 32 : 0;
+    a.split_from = (!split && e1) ? 32 : 0;   // (a multiple of every ring depth the split kernels are launched with: 4 and 8)
     for (int j = 0; j < a.jobs; ++j) {
       a.in_step0[j] = 0;
       a.out_col0[j] = 32 * a.nb_stage * j;
     }
 #define NLML_HXS_LAUNCH(NB, R)                                                               \
   do {                                                                                       \
-    if (split) hipLaunchKernelGGL((layer_kernel<NB, R, true>), grid, block, 0, st, a);       \
-    else hipLaunchKernelGGL((layer_kernel<NB, R, false>), grid, block, 0, st, a);            \
+    if (!use_split) hipLaunchKernelGGL((layer_kernel<NB, R, 0>), grid, block, 0, st, a);        \
+    else if (a.split_from == 0) hipLaunchKernelGGL((layer_kernel<NB, R, 1>), grid, block, 0, st, a); \
+    else hipLaunchKernelGGL((layer_kernel<NB, R, 2>), grid, block, 0, st, a);                   \
   } while (0)
     // blocks per wave: as many as still leave enough waves to keep the weight loads of every CU in flight
     int nbw = a.nb_stage;
-    if (split && nbw > 2) nbw = 2;    // two accumulator sets per block: four blocks per wave would not fit the register file
+    if (use_split && nbw > 2) nbw = 2;    // two accumulator sets per block: four blocks per wave would not fit the register file
     constexpr int kMinUnits = 2048;   // measured: 8 waves per CU keep enough loads in flight (256 units: 153 us at B = 2,000; 2,048: 114 us)
     while (nbw > 1 && (int64_t)ntiles * a.jobs * (a.nb_stage / nbw) < kMinUnits) nbw >>= 1;
     const int64_t units = (int64_t)ntiles * a.jobs * (a.nb_stage / nbw);

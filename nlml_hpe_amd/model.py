@@ -22,8 +22,8 @@ class HIPPoseModel:
         """mode (int constant or name):
           _lib.MODE_F16X2 "f16x2"  (default) the fast mode, on the f16 matrix cores: every f32 operand as two f16 pieces; ~1e-5 deg
                                    from the reference on small poses, and at the reference's operating range (poses to
-                                   +-60 deg, FX3c) 2.1e-5 / 6.7e-5 / 1.26e-4 deg from the exact result in p50 / p99 / max =
-                                   1.23x the reference's own distance, 0.05 % of the faces beyond 1e-4 deg; 3x the faces/s
+                                   +-60 deg, FX3c) 1.86e-5 / 5.9e-5 / 1.22e-4 deg from the exact result in p50 / p99 / max =
+                                   1.10 / 1.08 / 1.24x the reference's own distance, 0.024 % of the faces beyond 1e-4 deg; 3x the faces/s
                                    of the f32 mode; a face whose activations leave f16's range is re-evaluated in f32 inside
                                    the same launch (no input-range limit; ~40x slower if EVERY face does);
           _lib.MODE_F16X2S "f16x2s" the strict-fast mode: f16x2's operands and matrix instructions, the small products of

@@ -970,14 +970,14 @@ def test_fx3c_no_worse_than_the_reference_itself(mode, head_sds, golden_dir, dev
             kernel_vs_ref_max=vs_ref["max"], kernel_vs_ref_frac_above=vs_ref["frac_above_1e-4"],
             ref_batch1_vs_batched_max=ref_self["max"], ref_batch1_vs_batched_frac_above=ref_self["frac_above_1e-4"])
     # f32 kernel (layers 0 to 3 summed in blocks of 128 k): no worse than the reference in every statistic, nothing beyond 1e-4 deg.
-    # split-f16 kernel: 1.23-1.27x the reference's distance from the truth (measured; its layer-0 / layer-1 accumulators round
-    # 264 / 192 times per dot product at full magnitude and there is no register room for block sums), 0.05 % of the faces
-    # beyond 1e-4 deg of the truth, max 1.26e-4 deg.  Bounds = measured + 20 %, not looser.
+    # split-f16 kernel (the fast mode): 1.10 / 1.08 / 1.24x the reference's distance from the truth in p50 / p99 / max (measured: 1.86e-5 /
+    # 5.88e-5 / 1.22e-4 deg; layer 0 and layer 1's first K half run on single accumulators -- no register for a second set in the
+    # one-pass form -- the rest on split ones), 0.024 % of the faces beyond 1e-4 deg of the truth.  Bounds = measured + 20 %, not looser.
     # strict-fast kernel (f16x2s: the small products of each K step accumulate apart in layers 0 to 2): measured 1.49e-5 /
     # 4.65e-5 / 9.2e-5 deg = 0.85-0.93x the reference's distance: held to the f32 kernel's bounds.
-    ratio = {"f32": 1.05, "f16x2s": 1.05, "f16x2": 1.5}[mode]
-    for s_ in ("p50", "p99", "max"):
-        assert k[s_] <= ratio * r[s_], (mode, s_, k, r)
+    ratio = {"f32": (1.05, 1.05, 1.05), "f16x2s": (1.05, 1.05, 1.05), "f16x2": (1.32, 1.30, 1.49)}[mode]
+    for s_, q_ in zip(("p50", "p99", "max"), ratio):
+        assert k[s_] <= q_ * r[s_], (mode, s_, k, r)
     if mode == "f16x2s":
         # nothing beyond 1e-4 deg of the truth.  Against the reference's batched output: two evaluations with INDEPENDENT errors of
         # 1.5e-5 and 1.7e-5 deg p50 -- 0.073 % of the faces differ by more than 1e-4 deg, max 1.34e-4 deg (measured; bounds +20 %).
@@ -991,8 +991,8 @@ def test_fx3c_no_worse_than_the_reference_itself(mode, head_sds, golden_dir, dev
         # 0.012 %, 1.23e-4 deg)
         assert vs_ref["max"] <= 1.45e-4 and vs_ref["frac_above_1e-4"] <= ref_self["frac_above_1e-4"] + 2.0 / len(x), (vs_ref, ref_self)
     else:
-        assert k["max"] <= 1.5e-4 and k["frac_above_1e-4"] <= 6e-4, k
-        assert vs_ref["max"] <= 2.2e-4 and vs_ref["frac_above_1e-4"] <= 4.2e-3, vs_ref
+        assert k["max"] <= 1.47e-4 and k["frac_above_1e-4"] <= 3e-4, k
+        assert vs_ref["max"] <= 2.0e-4 and vs_ref["frac_above_1e-4"] <= 2.1e-3, vs_ref       # measured 1.67e-4 deg, 0.17 %
 
 
 @pytest.mark.parametrize("mode", ["f16x2", "f16x2s", "f32"])
@@ -1329,7 +1329,7 @@ def test_bench_line_carries_the_contract_fields(mode, repo_root, device):
     if mode == "f16x2s":    # the strict-fast mode: inside the reference's own distance from the truth
         assert k_["p50_deg"] <= 1.05 * r_["p50_deg"] and k_["max_deg"] <= POSE_TOL_DEG and k_["frac_above_1e-4_deg"] == 0.0
     else:
-        assert k_["p50_deg"] <= 1.5 * r_["p50_deg"] and k_["max_deg"] <= 1.5e-4
+        assert k_["p50_deg"] <= 1.32 * r_["p50_deg"] and k_["max_deg"] <= 1.47e-4
 
 
 def test_bench_two_rank_path_on_one_gpu(repo_root, device):
