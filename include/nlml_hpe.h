@@ -140,7 +140,7 @@ int nlml_landmarks_to_pose(const float* raw, int64_t B, int normalize,
 
 /* The same forward for SMALL batches in NLML_MODE_F16X2 / NLML_MODE_F16X2S: the three big layers as one launch each over (neuron blocks x
  * 64-face tiles) plus one launch for the tail, instead of one CU per tile, so 64 or 2,000 faces use the whole chip (a
- * 64-face video tick: 0.064 ms instead of 0.17 ms); the results are bit-identical to nlml_encoder_heads_fwd / nlml_landmarks_to_pose with the same blob.
+ * 64-face video tick: 0.06 ms instead of 0.17 ms); the results are bit-identical to nlml_encoder_heads_fwd / nlml_landmarks_to_pose with the same blob.
  * Activations pass between the launches through `workspace` (device memory, 16-byte aligned, at least
  * nlml_encoder_heads_small_workspace_bytes(B, F) bytes, contents irrelevant before and after); stream order is the only
  * synchronisation, so the sequence can be captured into a hipGraph.  Above ~8,000 faces the fused entry points are faster.

@@ -224,7 +224,6 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         mma3(r, sp_c);
         __builtin_amdgcn_sched_barrier(0);
-        if (SPLIT && g * R + r + 1 == a.fold_step) fold(true);   // (fold_step 0: never)
       }
     }
   };
@@ -233,17 +232,22 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
     run_groups(0, gs, std::false_type{});
     run_groups(gs, groups4, std::true_type{});
   } else if constexpr (SPLITK == 1) {
-    run_groups(0, groups4, std::true_type{});
+    // the mid-way fold sits BETWEEN two group loops (fold_step is a multiple of R, launcher): a test per step inside one loop makes
+    // every step a basic block of its own, and hipcc then moves both accumulator sets between the register files around each
+    // (128-192 v_accvgpr moves per 6 MFMAs: the split layers ran 25 % slower than the plain ones)
+    const int gf = a.fold_step > 0 && a.fold_step / R < groups4 ? a.fold_step / R : groups4;
+    run_groups(0, gf, std::true_type{});
+    if (gf < groups4) {
+      fold(true);
+      run_groups(gf, groups4, std::true_type{});
+    }
   } else {
     run_groups(0, groups4, std::false_type{});
   }
   const int tail = K16 - groups4 * R;   // steps groups4*R + r sit in slot r (loaded D steps earlier, or by the prologue)
 #pragma unroll
   for (int r = 0; r < R - 1; ++r)
-    if (r < tail) {
-      mma(r, groups4 * R + r);
-      if (SPLIT && groups4 * R + r + 1 == a.fold_step) fold(true);
-    }
+    if (r < tail) mma(r, groups4 * R + r);
 
   fold(false);
   const float inv = hdr->inv_scale[st];
@@ -347,17 +351,20 @@ int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* r
     //   NLML_MODE_F16X2:  layer 1 from its K midpoint on, layer 2; layer 0 never (kernel without the second set)
     const bool e0 = stages[s].stage == ST_E0, e1 = stages[s].stage == ST_E1;
     const bool use_split = split || !e0;
-    a.fold_step = (split && e1) ? 32 : 0;
+    a.fold_step = (split && e1) ? 32 : 0;     // (like split_from a multiple of the split kernels' ring depths, 4 and 8)
     a.split_from = (!split && e1) ? 32 : 0;   // (a multiple of every ring depth the split kernels are launched with: 4 and 8)
     for (int j = 0; j < a.jobs; ++j) {
       a.in_step0[j] = 0;
       a.out_col0[j] = 32 * a.nb_stage * j;
     }
-#define NLML_HXS_LAUNCH(NB, R)                                                               \
-  do {                                                                                       \
-    if (!use_split) hipLaunchKernelGGL((layer_kernel<NB, R, 0>), grid, block, 0, st, a);        \
-    else if (a.split_from == 0) hipLaunchKernelGGL((layer_kernel<NB, R, 1>), grid, block, 0, st, a); \
-    else hipLaunchKernelGGL((layer_kernel<NB, R, 2>), grid, block, 0, st, a);                   \
+#ifndef HXS_RS1
+#define HXS_RS1 8
+#endif
+#define NLML_HXS_LAUNCH(NB, R, RS)                                                                   \
+  do {                                                                                               \
+    if (!use_split) hipLaunchKernelGGL((layer_kernel<NB, R, 0>), grid, block, 0, st, a);             \
+    else if (a.split_from == 0) hipLaunchKernelGGL((layer_kernel<NB, RS, 1>), grid, block, 0, st, a); \
+    else hipLaunchKernelGGL((layer_kernel<NB, R, 2>), grid, block, 0, st, a);                        \
   } while (0)
     // blocks per wave: as many as still leave enough waves to keep the weight loads of every CU in flight
     int nbw = a.nb_stage;
@@ -367,14 +374,14 @@ int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* r
     const int64_t units = (int64_t)ntiles * a.jobs * (a.nb_stage / nbw);
     if (units < 1024) {   // fewer than four waves per CU: one wave per workgroup, deep ring
       const dim3 grid((unsigned)units), block(64);
-      if (nbw == 4) NLML_HXS_LAUNCH(4, 6);
-      else if (nbw == 2) NLML_HXS_LAUNCH(2, 8);
-      else NLML_HXS_LAUNCH(1, 8);
+      if (nbw == 4) hipLaunchKernelGGL((layer_kernel<4, 6, 0>), grid, block, 0, st, a);   // (four blocks per wave: layer 0 without a second set only)
+      else if (nbw == 2) NLML_HXS_LAUNCH(2, 8, HXS_RS1);
+      else NLML_HXS_LAUNCH(1, 8, HXS_RS1);
     } else {
       const dim3 grid((unsigned)((units + 3) / 4)), block(256);
-      if (nbw == 4) NLML_HXS_LAUNCH(4, 4);
-      else if (nbw == 2) NLML_HXS_LAUNCH(2, 4);
-      else NLML_HXS_LAUNCH(1, 4);
+      if (nbw == 4) hipLaunchKernelGGL((layer_kernel<4, 4, 0>), grid, block, 0, st, a);
+      else if (nbw == 2) NLML_HXS_LAUNCH(2, 4, 4);
+      else NLML_HXS_LAUNCH(1, 4, 4);
     }
 #undef NLML_HXS_LAUNCH
     h8* t = in; in = outb; outb = t;

@@ -1,10 +1,11 @@
 """Latency of the layer-per-launch K2 path at 64 / 512 / 2,000 / 4,096 faces, both split-f16 modes (A/B of builds on ONE box:\nfor L in exp_libs/a.so exp_libs/b.so; do NLML_HPE_LIB=$L python tools/k2_small_ab.py; done).  Development aid."""
 import os, sys
-sys.path.insert(0, os.getcwd())
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch
 from nlml_hpe_amd import ops, synth, weights, _lib
 dev = torch.device("cuda:0")
-heads = weights.load_head_state_dicts("models")
+heads = weights.load_head_state_dicts(os.path.join(ROOT, "models"))
 def ms_of(fn, n=300, warm=100):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
