@@ -308,8 +308,18 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
     const int n = t / (TR_LEAVES * 8), L = (t / 8) % TR_LEAVES, jj = t % 8;
     const __attribute__((address_space(3))) double* a = rl->d2[n] + tr_leaf_start(L);
     const int len = tr_leaf_len(L), body = len - (len % 8);
-    double r = a[jj];
-    for (int i2 = 8 + jj; i2 < body; i2 += 8) r += a[i2];
+    // 10 or 11 elements (leaves of 80 / 88 / 92): all reads first (a loop with a run-time trip count waits for every LDS read on
+    // its own: 1.1 k ticks per sum), then the adds in numpy's order; the surplus read of a 10-element sum is a clamped re-read
+    const int nq = body >> 3;
+    double v[11];
+#pragma unroll
+    for (int q = 0; q < 11; ++q) v[q] = a[jj + 8 * (q < nq ? q : nq - 1)];
+    double r = v[0];
+#pragma unroll
+    for (int q = 1; q < 11; ++q) {
+      const double r1 = r + v[q];
+      r = q < nq ? r1 : r;
+    }
     rl->leaf8[n][L][jj] = r;
   }
   __syncthreads();
@@ -321,7 +331,15 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
     double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
     const __attribute__((address_space(3))) double* a = rl->d2[n] + tr_leaf_start(L);
     const int len = tr_leaf_len(L);
-    for (int i2 = len - (len % 8); i2 < len; ++i2) res += a[i2];
+    const int rem = len & 7, b8 = len - rem;            // 0 or 4 remainder elements
+    double w4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w4[q] = a[q < rem ? b8 + q : 0];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double r1 = res + w4[q];
+      res = q < rem ? r1 : res;
+    }
     rl->leaf[n][L] = res;
   }
   __syncthreads();
