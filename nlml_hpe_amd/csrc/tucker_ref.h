@@ -178,6 +178,26 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
   __builtin_amdgcn_sched_barrier(0);
   wload(0, wr[0]);
   wload(1, wr[1]);
+#ifndef TR_NO_XPREFETCH
+  // this thread's x values ride with the prologue's loads and wait in the d2 slots they will be subtracted in (as f32 in the low
+  // half of the slot: written and read by the same thread) -- at the end of the main loop they used to be one exposed round trip
+  // to global memory for the wave that finishes last
+  {
+    float xv[TR_COLS][NE];
+#pragma unroll
+    for (int n = 0; n < NE; ++n) {
+      const float* xr = xrow((slots >> (4 * n)) & 15);
+#pragma unroll
+      for (int c = 0; c < TR_COLS; ++c)
+        xv[c][n] = (livec[c] && (c == 0 || (n >= c1_lo && n < c1_hi))) ? gload<float>(xr + mc[c]) : 0.0f;
+    }
+#pragma unroll
+    for (int n = 0; n < NE; ++n)
+#pragma unroll
+      for (int c = 0; c < TR_COLS; ++c)
+        if (livec[c] && (c == 0 || (n >= c1_lo && n < c1_hi))) *(__attribute__((address_space(3))) float*)&rl->d2[n][mc[c]] = xv[c][n];
+  }
+#endif
   __builtin_amdgcn_sched_barrier(0);
   if (tid < NE * TR_NFAC) rl->fac[tid / TR_NFAC][tid % TR_NFAC] = facv;
   __syncthreads();
@@ -296,7 +316,11 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
 #pragma unroll
     for (int c = 0; c < TR_COLS; ++c)
       if (livec[c] && (c == 0 || (n >= c1_lo && n < c1_hi))) {
+#ifndef TR_NO_XPREFETCH
+        const double d = (double)*(const __attribute__((address_space(3))) float*)&rl->d2[n][mc[c]] - acc[c][n];
+#else
         const double d = (double)gload<float>(xr + mc[c]) - acc[c][n];
+#endif
         rl->d2[n][mc[c]] = d * d;
         if (xh) xh[mc[c]] = acc[c][n];
       }
