@@ -143,14 +143,22 @@ __global__ __launch_bounds__(ORDER == NLML_TD_ORDER_REFERENCE ? TR_NT : TNT, ORD
 
     if constexpr (ORDER == NLML_TD_ORDER_REFERENCE) {
       __shared__ __attribute__((aligned(16))) TuckerRefShared rs;
+      PWS(0);
       tucker_fvec(sh, lp, cp4, tid);
+      PWS(1);
       tucker_ref_eval(sh, rs, Wm, lp, live_mask, PowellXRow{x, ldx, e0, N}, NoXhRow{}, tid);
+      PWS(2);
       if (me >= 0 && need[me]) {
-        const bool nd = powell_step_call((LdsPowellState*)&st[me], rs.err[me]);
+        const double fe = rs.err[me];
+        PWS(4);
+        const bool nd = powell_step_call((LdsPowellState*)&st[me], fe);
+        PWS(5);
         need[me] = nd ? 1 : 0;
         if (nd) atomicOr(&livew[(round + 1) & 1], 1 << me);
+        PWS(6);
       }
       __syncthreads();
+      PWS(3);
     } else {   // NLML_TD_ORDER_FAST (discarded in the other instantiation: its LDS is the reference pass's)
     __shared__ __attribute__((aligned(16))) TuckerFewShared few;
     PWS(0);

@@ -1,4 +1,4 @@
-"""Per-phase cycles of a Powell round from the -DPW_STAMPS diagnostic build.  usage: NLML_HPE_LIB=exp_libs/pw_stamps.so python tools/powell_phases.py"""
+"""Per-phase cycles of a Powell round from the -DPW_STAMPS diagnostic build.  usage: NLML_HPE_LIB=exp_libs/pw_stamps.so python tools/powell_phases.py [fast|reference]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,7 +13,7 @@ for copies in (1, 3, 16):
     X = Xg[:1].repeat(copies, 1).contiguous()
     if copies < 8:
         X = torch.cat([X, Xg[1:9 - copies]])        # pad the workgroup to >= 8 faces so that fval[0..7] exist (the extra faces finish early)
-    res = ops.tucker_powell(Wm, X, cp, order="fast")
+    res = ops.tucker_powell(Wm, X, cp, order=(sys.argv[1] if len(sys.argv) > 1 else "fast"))
     torch.cuda.synchronize()
     ph8 = res["fun"][:8].cpu().numpy()
     ph = ph8[:4]
