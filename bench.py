@@ -337,7 +337,8 @@ def main():
             sample = np.arange(0, B, max(1, B // 2048))[:2048]
             got = step_fn()[torch.from_numpy(sample).to(dev)].cpu().numpy()
             rec["cpu_baseline"] = cpu_baseline(raw_np, sd, heads, args.cpu_seconds, sample, got)
-            rec["cpu_baseline"]["parity_check_operating_range"] = parity_operating_range(ops, weights, dev, heads, mode, args.mode)
+            others = [] if args.no_extra else [(_lib.mode_from_name(m), m) for m in ("f16x2", "f16x2s", "f32") if m != args.mode]
+            rec["cpu_baseline"]["parity_check_operating_range"] = parity_operating_range(ops, weights, dev, heads, mode, args.mode, others)
             if not args.no_extra:
                 rec["cpu_baseline"]["td_path"] = td_cpu_baseline(weights, synth)
         if world == 1 and not args.no_extra and B == 65536:    # the secondary workloads are defined on the 65,536-face batch
@@ -402,7 +403,7 @@ def cpu_baseline(raw_np, sd, heads, seconds, sample, got):
                              "mean_abs_deg": float(err.mean()), "tolerance_deg": 1e-4}}
 
 
-def parity_operating_range(ops, weights, dev, heads, mode, mode_name):
+def parity_operating_range(ops, weights, dev, heads, mode, mode_name, also=()):
     """The measured kernel where the reference operates (FX3c: FX3b's weights -- latent over the rows of U_yaw/U_pitch/U_roll,
     poses over the trained +-50/40/30 deg bins -- on 16,384 Philox faces): p50 / p99 / max of |kernel - f64 truth| per face, next
     to the same statistics of the REFERENCE's own outputs (tests/golden/fx3c_reference_range_16k.npz: its batched and its
@@ -422,8 +423,13 @@ def parity_operating_range(ops, weights, dev, heads, mode, mode_name):
         d = np.degrees(np.abs(y.astype(np.float64) - ref.astype(np.float64))).max(axis=1)
         return {"p50_deg": float(np.percentile(d, 50)), "p99_deg": float(np.percentile(d, 99)), "max_deg": float(d.max()),
                 "frac_above_1e-4_deg": float((d > 1e-4).mean())}
+    other = {}
+    for m2, name2 in also:     # the other K2 modes on the same faces (not the timed kernel): kernel vs truth and vs the reference
+        b2 = torch.from_numpy(weights.pack_blob(sd, heads, m2)).to(dev)
+        g2 = ops.encoder_heads_fwd(torch.from_numpy(x).to(dev), b2, 1404).cpu().numpy()
+        other[name2] = {"kernel_vs_f64_truth": stats(g2, truth), "kernel_vs_reference_batched": stats(g2, g3c["rad"])}
     return {"faces": 16384, "mode": mode_name, "pose_span_deg": [float(np.degrees(truth.min())), float(np.degrees(truth.max()))],
-            "kernel_vs_f64_truth": stats(got, truth),
+            "kernel_vs_f64_truth": stats(got, truth), "other_modes": other,
             "reference_batched_vs_f64_truth": stats(g3c["rad"], truth),
             "reference_batch1_vs_f64_truth": stats(g3c["rad_b1"], truth),
             "kernel_vs_reference_batched": stats(got, g3c["rad"]),
