@@ -197,7 +197,7 @@ def main():
     feats = ops.normalize_ipd(raw, True)
 
     # up to SMALL_BATCH_MAX faces the split-f16 mode runs layer per launch (what HIPPoseModel does; same bits as the fused kernel)
-    layered = args.mode in ("f16x2", "f16x2s") and 0 < B <= HIPPoseModel.SMALL_BATCH_MAX
+    layered = 0 < B <= HIPPoseModel.small_batch_max(args.mode)
     if args.path == "fused":
         fwd = ops.landmarks_to_pose_small if layered else ops.landmarks_to_pose
         step_fn = lambda: fwd(raw, blob, True)

@@ -73,12 +73,20 @@ class HIPPoseModel:
         return fwd(x.to(self.device, torch.float32), self.blob, self.input_size,
                    return_latent=return_latent, return_valid=return_valid)
 
-    SMALL_BATCH_MAX = 4096
+    SMALL_BATCH_MAX = 4096          # NLML_MODE_F16X2: above this the fused kernel wins (5,120 faces: 0.140 against 0.159 ms)
+    SMALL_BATCH_MAX_STRICT = 8192   # NLML_MODE_F16X2S: its fused kernel is slower per tile (8,192 faces: 0.201 against 0.192 ms layered)
+
+    @classmethod
+    def small_batch_max(cls, mode) -> int:
+        """Largest batch the layer-per-launch path takes in `mode` (0 for the modes that have no such path); measured crossovers,
+        tools/k2_crossover.py."""
+        mode = _lib.mode_from_name(mode)
+        return {_lib.MODE_F16X2: cls.SMALL_BATCH_MAX, _lib.MODE_F16X2S: cls.SMALL_BATCH_MAX_STRICT}.get(mode, 0)
 
     def _small(self, B: int) -> bool:
-        """Split-f16 mode, up to SMALL_BATCH_MAX faces: the layer-per-launch path (same bits as the fused kernel, 0.06-0.13 ms
-        instead of 0.17 ms because a handful of 64-face tiles cannot fill 256 CUs with one CU per tile)."""
-        return self.mode in (_lib.MODE_F16X2, _lib.MODE_F16X2S) and 0 < B <= self.SMALL_BATCH_MAX
+        """Split-f16 modes, up to small_batch_max(mode) faces: the layer-per-launch path (same bits as the fused kernel, 0.06-0.13 ms
+        instead of 0.14-0.20 ms because a handful of 64-face tiles cannot fill 256 CUs with one CU per tile)."""
+        return 0 < B <= self.small_batch_max(self.mode)
 
     def from_landmarks(self, raw: torch.Tensor, normalize: bool = True, return_latent: bool = False,
                        return_valid: bool = False):

@@ -875,7 +875,7 @@ def test_model_dispatches_small_batches_and_graph_replays(hx, head_sds, device):
     sd = synth.encoder_state_dict(1404, seed=0)
     model = HIPPoseModel(sd, head_sds, device=device, mode=hx)
     raw = torch.from_numpy(synth.raw_landmarks(300, seed=8)).to(device)
-    assert model._small(300) and not model._small(model.SMALL_BATCH_MAX + 1)
+    assert model._small(300) and not model._small(model.small_batch_max(hx) + 1) and model.small_batch_max("f32") == 0
     assert torch.equal(model.from_landmarks(raw), ops.landmarks_to_pose(raw, model.blob, True))
     feats = ops.normalize_ipd(raw, True)
     assert torch.equal(model.forward_packed(feats), ops.encoder_heads_fwd(feats, model.blob, 1404))
