@@ -22,7 +22,7 @@ print("ticks per workgroup, both passes (wave mean): %.0f   gap between the pass
 for i, n in enumerate(names):
     print(f"  {n:34s} {d[..., i].mean():10.0f} ticks per pass  ({100 * 2 * d[..., i].mean() / tot.mean():.1f} %)")
 print("  main loop by wave (ticks, mean over workgroups and passes; waves w, w+4, w+8 share a SIMD):", " ".join("%d" % v for v in d[..., 1].mean(axis=(0, 1))))
-print("  end of main loop relative to pass start, by wave:", " ".join("%d" % v for v in (st[..., 2] - st[..., 0:1].min(axis=2, keepdims=True)[..., 0:1].repeat(12, axis=2)[..., 0] if False else (st[..., 2] - st[..., 0].min(axis=2, keepdims=True)).mean(axis=(0, 1)))))
+print("  end of main loop relative to pass start, by wave:", " ".join("%d" % v for v in (st[..., 2] - st[..., 0].min(axis=2, keepdims=True)).mean(axis=(0, 1))))
 G = N // 16
 ks = xh.cpu().numpy().view(np.uint64).reshape(-1)[G * 192: G * 192 + G * 8].reshape(G, 8).astype(np.int64)
 dt_ticks, dt_real = (ks[:, 3] - ks[:, 0]).mean(), (ks[:, 5] - ks[:, 4]).mean()
