@@ -23,7 +23,7 @@ def model_builder(argv=None):
     ap.add_argument("--synthetic-encoder-seed", type=int, default=None,
                     help="use generator-G encoder weights when models/Encoder.pth is absent (the reference ships none)")
     ap.add_argument("--out", default="models/combined_model_packed.nlml")
-    ap.add_argument("--mode", choices=["f16x2", "f16x2s", "f32", "bf16"], default="f16x2",
+    ap.add_argument("--mode", choices=["f16x2s", "f32", "f16x2", "bf16"], default="f16x2s",
                     help="kernel mode the blob is packed for (the forward entry points recognise it by the blob size)")
     args = ap.parse_args(argv)
 

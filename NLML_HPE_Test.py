@@ -30,9 +30,9 @@ def NLML_HPE_Tester(argv=None):
     ap.add_argument("--device", default=None)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--mode", choices=["f16x2", "f16x2s", "f32", "bf16"], default=None,
-                    help="kernel mode (default: NLML_HPE_MODE or f16x2 = the fast mode, 1.10x the reference's own distance from the exact result at "
-                         "+-45 deg poses; f16x2s = strict-fast: the same operands with split accumulators, inside the reference's own distance at 0.78x the rate; "
-                         "f32 = the strict parity mode on the f32 cores, no further out than the reference; bf16 = throughput only, ~0.1 deg)")
+                    help="kernel mode (default: NLML_HPE_MODE or f16x2s = strict-fast: split-f16 operands with split accumulators on the f16 matrix "
+                         "cores, inside the reference's own distance from the exact result; f32 = the strict parity mode on the f32 cores; "
+                         "f16x2 = opt-in, 1.10x the reference's error at +-45 deg poses; bf16 = throughput only, ~0.1 deg)")
     args = ap.parse_args(argv)
     warnings.filterwarnings("default")
 

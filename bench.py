@@ -10,9 +10,10 @@
 One STEP = one pass of the hot path over one batch that is already resident in HBM:
 raw landmarks f32[B,468,3] -> IPD normalisation -> encoder -> 3 heads -> (yaw,pitch,roll) f32[B,3],
 one fused HIP launch per rank (nlml_landmarks_to_pose), B = 65,536 faces per GPU (weak scaling),
-F = 1404 (the reference's real feature width).  --mode picks the kernel: f16x2 (default: split-f16 operands on the
-f16 matrix cores, f32 accumulate; ~1e-5 deg from the reference on small poses, 1.10x the reference's own distance from the exact
-result at +-45 deg poses) or f32 (f32 matrix cores with blocked sums: the strict parity mode, 1/3 of the rate).  With N > 1 every
+F = 1404 (the reference's real feature width).  --mode picks the kernel: f16x2s (DEFAULT: split-f16 operands on the
+f16 matrix cores with split accumulators, f32 accumulate -- the strict-fast mode: at the reference's operating range no farther from
+the exact result than the reference's own f32 forward), f32 (f32 matrix cores with blocked sums: the strict parity mode) or f16x2
+(opt-in: single accumulators where registers are short, 1.10x the reference's error at +-45 deg poses).  With N > 1 every
 step also all-gathers the [B,3] poses of all ranks over RCCL (the only collective the path has),
 on the communication stream, overlapped with the next step's compute; a second timed region of K steps without
 the collective gives `value_no_collective` (--no-collective: time only that one).
@@ -62,13 +63,17 @@ def parse():
     ap.add_argument("--batch", type=int, default=65536, help="faces per GPU per step")
     ap.add_argument("--path", choices=["fused", "features"], default="fused",
                     help="fused: raw landmarks in (K1+K2 in one launch); features: normalised features in (K2)")
-    ap.add_argument("--mode", choices=["f16x2", "f16x2s", "f32"], default="f16x2",
-                    help="kernel: f16x2 = split-f16 operands on the f16 matrix cores (fast default); f16x2s = the same with split accumulators (strict-fast); f32 = f32 matrix cores, blocked sums (strict parity)")
+    ap.add_argument("--mode", choices=["f16x2s", "f32", "f16x2"], default="f16x2s",
+                    help="kernel: f16x2s = split-f16 operands on the f16 matrix cores, split accumulators (strict-fast, the default); "
+                         "f32 = f32 matrix cores, blocked sums (strict parity); f16x2 = opt-in, 1.10x the reference's error")
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="that many untimed steps (~1 ms each) BEFORE the W warm-up steps, so that short K/W also measure "
                          "the sustained (power-limited) rate; reported in the JSON as config.settle_ms")
     ap.add_argument("--no-collective", action="store_true",
                     help="N > 1: no all-gather in the timed steps (default: time with it and report value_no_collective beside)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic on this box (traffic: null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child of measure_traffic(): a few launches, no output
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -155,10 +160,72 @@ def spawn_ranks(n: int, script: str = None, argv: list = None) -> int:
     return rc
 
 
+K2_KERNEL_MARKS = ("encoder_heads_", "prepass_kernel", "layer_kernel", "tail_kernel")   # the kernels of one K2 step
+PMC_CHILD_WARM, PMC_CHILD_STEPS = 3, 10
+
+
+def under_profiler() -> bool:
+    return bool(os.environ.get("ROCP_TOOL_LIBRARIES")) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+def measure_traffic(args):
+    """roofline.traffic, measured ON THIS BOX IN THIS RUN: HBM-side bytes per step of the timed K2 kernel(s) from the TCC counters,
+    collected and corrected as MI355X_MICROARCH.md's HBM section prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc
+    passes (nothing else traced), FETCH_SIZE doubled on gfx950 (it tallies the 128-byte requests of a wide coalesced stream at 64 bytes),
+    both in KiB: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Each pass is a CHILD process (`rocprofv3 --pmc C -- python3 bench.py
+    --pmc-child ...`: the same batch, blob and launch, 3 + 10 steps, nothing printed) started before this process has touched the
+    GPU.  Returns (bytes_per_step or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if under_profiler():
+        return None, "not measured: this process runs under a profiler preload (a child start from here would be an exec after GPU init)"
+    tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(tool):
+        return None, "not measured: rocprofv3 not found"
+    per_step = {}
+    t0 = time.time()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix=f"nlml_pmc_{counter}_", dir="/tmp")
+        cmd = [tool, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+               "--pmc-child", "--mode", args.mode, "--path", args.path, "--batch", str(args.batch)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.PIPE, timeout=240)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(out, ignore_errors=True)
+            return None, f"not measured: the {counter} pass did not finish in 240 s"
+        vals = []
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row.get("Counter_Name") == counter and any(m in row.get("Kernel_Name", "") for m in K2_KERNEL_MARKS):
+                    vals.append((int(row.get("Dispatch_Id", 0)), float(row["Counter_Value"])))
+        shutil.rmtree(out, ignore_errors=True)
+        if r.returncode != 0 or not vals:
+            tail = (r.stderr or b"")[-300:].decode(errors="replace").replace("\n", " | ")
+            return None, f"not measured: the {counter} pass returned {r.returncode} with {len(vals)} kernel rows ({tail})"
+        vals.sort()
+        n_total = PMC_CHILD_WARM + PMC_CHILD_STEPS
+        if len(vals) % n_total:
+            return None, f"not measured: {len(vals)} kernel rows in the {counter} pass do not divide into {n_total} steps"
+        per = len(vals) // n_total                          # kernels per step (1 fused, 5 layer-per-launch)
+        timed = vals[PMC_CHILD_WARM * per:]
+        per_step[counter] = sum(v for _, v in timed) / PMC_CHILD_STEPS
+    b = (2.0 * per_step["FETCH_SIZE"] + per_step["WRITE_SIZE"]) * 1024.0
+    return b, (f"measured in this run on this box: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate child passes of the same "
+               f"launch ({PMC_CHILD_STEPS} steps after {PMC_CHILD_WARM}), (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md; "
+               f"FETCH_SIZE {per_step['FETCH_SIZE']:.0f} KiB, WRITE_SIZE {per_step['WRITE_SIZE']:.0f} KiB per step; {time.time() - t0:.0f} s")
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
+    traffic, traffic_source = None, "not measured (N > 1, --no-traffic or --pmc-child)"
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_traffic and not args.pmc_child:
+        traffic, traffic_source = measure_traffic(args)     # child processes, before anything here touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -204,6 +271,12 @@ def main():
     else:
         fwd = ops.encoder_heads_fwd_small if layered else ops.encoder_heads_fwd
         step_fn = lambda: fwd(feats, blob, F)
+
+    if args.pmc_child:        # measure_traffic()'s child: the timed launch a few times under rocprofv3 --pmc, nothing else
+        for _ in range(PMC_CHILD_WARM + PMC_CHILD_STEPS):
+            step_fn()
+        torch.cuda.synchronize()
+        return
 
     gatherer = PoseGatherer(B, world, dev) if world > 1 else None
     comm_info = None
@@ -280,20 +353,6 @@ def main():
     if rank == 0:
         value = world * B * args.steps / elapsed
         achieved = B * FLOP_PER_FACE[F] / (kern_ms * 1e-3) / 1e12
-        traffic, traffic_source = None, None
-        for tag in ("r03", "r02", "r01"):
-            tpath = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
-            if not os.path.exists(tpath) or layered:
-                continue
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(f"{args.mode}_{args.path}_bytes_per_launch")
-                if traffic is not None:
-                    traffic_source = (f"from profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc passes of this command at B=65536, "
-                                      f"kernel_ms {tj.get(f'{args.mode}_{args.path}_kernel_ms')}); not re-measured in this run")
-                    break
-            except Exception:
-                traffic = None
         if args.mode in ("f16x2", "f16x2s"):
             peak = PEAK_F16_MFMA_TFLOPS
             kernel = "k2s_* (pre, E0, E1, E2, tail: 5 launches)" if layered else "encoder_heads_f16x2_kernel"
@@ -302,10 +361,11 @@ def main():
                           "note": "each algorithmic product runs as 3 f16 MFMA products (hi*hi + hi*lo + lo*hi, f32 accumulate); "
                                   "frac counts the algorithmic FLOP only; at 65,536 faces the kernel runs at the board's power "
                                   "limit (clock ~1.9 GHz instead of 2.4), see DESIGN.md section 3"}
-            dtype = "f16x2"
-            what = "split-f16 mode (two f16 pieces per f32 operand, f32 accumulate; the fast default -- its error at the operating range is in cpu_baseline.parity_check_operating_range)"
-            if args.mode == "f16x2s":
-                what = "split-f16 strict-fast mode (f16x2's operands; the small products of each K step in accumulators of their own)"
+            dtype = args.mode
+            what = ("split-f16 strict-fast mode (two f16 pieces per f32 operand on the f16 matrix cores, f32 accumulate, the small products of each K step "
+                    "in accumulators of their own; the default: inside the reference's own error at the operating range, see cpu_baseline.parity_check_operating_range)")
+            if args.mode == "f16x2":
+                what = "split-f16 OPT-IN fast mode (single accumulators where registers are short): 1.10x the reference's error at the operating range -- not the parity default"
         else:
             peak, kernel, roof_extra, dtype, what = PEAK_F32_MFMA_TFLOPS, "encoder_heads_f32_kernel", {}, "f32", "f32 strict parity mode (layers 0-3 summed in blocks of 128 k)"
         rec = {
@@ -326,8 +386,14 @@ def main():
         }
         if cold_elapsed is not None:
             rec["value_cold"] = world * B * args.steps / cold_elapsed
-            rec["cold_note"] = (f"value_cold = the same K={args.steps} steps after only W={args.warmup} warm-ups, straight after "
-                                f"start-up; value = after {int(args.settle_ms)} more untimed steps (sustained, power-limited rate)")
+            rec["warmup_effective"] = args.warmup + args.steps + int(args.settle_ms) + args.warmup
+            rec["cold_note"] = (f"`warmup` is the flag as passed; the reported K steps are preceded by warmup_effective = {rec['warmup_effective']} "
+                                f"untimed-or-separately-timed steps: W={args.warmup} warm-ups + K={args.steps} steps timed as value_cold (straight after "
+                                f"start-up), {int(args.settle_ms)} settling steps (--settle-ms; the kernel runs at the board's power limit and the clock "
+                                f"needs ~0.25 s of load to reach its sustained level), then W={args.warmup} warm-ups again.  --settle-ms 0 makes "
+                                f"--warmup the only warm-up (value then equals value_cold's definition).")
+        else:
+            rec["warmup_effective"] = args.warmup
         if comm_info is not None:
             rec["comm"] = comm_info
         if nocoll_elapsed is not None:
@@ -427,15 +493,19 @@ def parity_operating_range(ops, weights, dev, heads, mode, mode_name, also=()):
     for m2, name2 in also:     # the other K2 modes on the same faces (not the timed kernel): kernel vs truth and vs the reference
         b2 = torch.from_numpy(weights.pack_blob(sd, heads, m2)).to(dev)
         g2 = ops.encoder_heads_fwd(torch.from_numpy(x).to(dev), b2, 1404).cpu().numpy()
-        other[name2] = {"kernel_vs_f64_truth": stats(g2, truth), "kernel_vs_reference_batched": stats(g2, g3c["rad"])}
+        other[name2] = {"kernel_vs_f64_truth": stats(g2, truth), "kernel_vs_reference_batched": stats(g2, g3c["rad"]),
+                        "kernel_vs_reference_batch1": stats(g2, g3c["rad_b1"])}
     return {"faces": 16384, "mode": mode_name, "pose_span_deg": [float(np.degrees(truth.min())), float(np.degrees(truth.max()))],
             "kernel_vs_f64_truth": stats(got, truth), "other_modes": other,
             "reference_batched_vs_f64_truth": stats(g3c["rad"], truth),
             "reference_batch1_vs_f64_truth": stats(g3c["rad_b1"], truth),
             "kernel_vs_reference_batched": stats(got, g3c["rad"]),
+            "kernel_vs_reference_batch1": stats(got, g3c["rad_b1"]),
             "reference_batch1_vs_reference_batched": stats(g3c["rad_b1"], g3c["rad"]),
             "note": "north_star's bar is 1e-4 deg against the reference's CPU output; at this range the reference's own two call "
-                    "shapes differ by up to 1.2e-4 deg, so the statement is statistical: kernel vs truth next to reference vs truth"}
+                    "shapes differ by up to 1.2e-4 deg, so the statement is statistical: kernel vs truth next to reference vs truth; "
+                    "kernel_vs_reference_batch1 is against the call shape the reference's entry points really use (one face per call, "
+                    "NLML_HPE_Test.py:262-272), kernel_vs_reference_batched against one batched call"}
 
 
 def td_cpu_baseline(weights, synth):
@@ -475,10 +545,12 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     sd136 = synth.encoder_state_dict(136, seed=0)
     x136 = torch.from_numpy(synth.features(B, 136, seed=1)).to(dev)
 
+    EV = "mean of one HIP event pair per launch, {n} launches after {w} warm-ups (torch's current stream)"
+
     def k2(fn, F, peak, products=1):
         ms = time_kernel(fn, 100, warm=30)
         tf = B * FLOP_PER_FACE[F] / ms / 1e9
-        d = {"faces_per_sec": B / ms * 1e3, "tflops": tf, "mfma_frac": tf / peak}
+        d = {"faces_per_sec": B / ms * 1e3, "tflops": tf, "mfma_frac": tf / peak, "timing": EV.format(n=100, w=30)}
         if products > 1:
             d["executed_frac"] = products * tf / peak
         return d
@@ -493,19 +565,23 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     ex["k2_f16x2_features_F1404"] = k2(lambda: ops.encoder_heads_fwd(feats, blob_hx, 1404), 1404, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
     blob136_hx = torch.from_numpy(weights.pack_blob(sd136, heads, _lib.MODE_F16X2)).to(dev)
     ex["k2_f16x2_features_F136"] = k2(lambda: ops.encoder_heads_fwd(x136, blob136_hx, 136), 136, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
-    # strict-fast mode: the same operands and MFMAs, split accumulators (layer 0 in two passes)
+    for k in ("k2_f16x2_fused_F1404", "k2_f16x2_features_F1404", "k2_f16x2_features_F136"):
+        ex[k]["parity_class"] = "OPT-IN fast mode: 1.10x the reference's error at the operating range (FX3c) -- not a strict parity figure"
+    # strict-fast mode (the default): the same operands and MFMAs, split accumulators
     blob_hxs = torch.from_numpy(weights.pack_blob(sd1404, heads, _lib.MODE_F16X2S)).to(dev)
     ex["k2_f16x2s_fused_F1404"] = k2(lambda: ops.landmarks_to_pose(raw, blob_hxs, True), 1404, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
-    del blob_hxs
+    ex["k2_f16x2s_features_F1404"] = k2(lambda: ops.encoder_heads_fwd(feats, blob_hxs, 1404), 1404, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
+    blob136_hxs = torch.from_numpy(weights.pack_blob(sd136, heads, _lib.MODE_F16X2S)).to(dev)
+    ex["k2_f16x2s_features_F136"] = k2(lambda: ops.encoder_heads_fwd(x136, blob136_hxs, 136), 136, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
     # (the blocks the two outputs will most likely be carved from are poisoned first: a launch that wrote nothing would otherwise
     # leave the previous call's pose in its torch.empty output and could show up as a difference of exactly 0)
     poison = [torch.full((B, 3), float("nan"), device=dev) for _ in range(2)]
     del poison
-    pose_hx, pose_f32 = ops.landmarks_to_pose(raw, blob_hx, True), ops.landmarks_to_pose(raw, blob, True)
+    pose_hx, pose_f32 = ops.landmarks_to_pose(raw, blob_hxs, True), ops.landmarks_to_pose(raw, blob, True)
     torch.cuda.synchronize()
     d = torch.rad2deg((pose_hx - pose_f32).abs())
     fin = bool(torch.isfinite(d).all())
-    ex["k2_f16x2_vs_f32_kernel_all_faces"] = {"max_abs_deg": float(d.max()) if fin else None,
+    ex["k2_f16x2s_vs_f32_kernel_all_faces"] = {"max_abs_deg": float(d.max()) if fin else None,
                                               "mean_abs_deg": float(d.mean()) if fin else None, "faces": B, "all_finite": fin,
                                               "distinct_buffers": pose_hx.data_ptr() != pose_f32.data_ptr()}
     # throughput mode (bf16 operands, f32 accumulate): NOT a parity result -- its measured error is reported with it
@@ -517,23 +593,24 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
                                      "bf16_mfma_frac": B * FLOP_PER_FACE[1404] / ms / 1e9 / PEAK_F16_MFMA_TFLOPS,
                                      "max_abs_deg_vs_f32_mode": float(torch.rad2deg(d.max())),
                                      "mean_abs_deg_vs_f32_mode": float(torch.rad2deg(d.mean())),
+                                     "timing": EV.format(n=100, w=30),
                                      "note": "throughput mode; fails the 1e-4 deg parity bar by design (SURVEY D3)"}
     # BASELINE config 4 per GPU: an AFLW2000-shaped stream, 2,000 faces per step (32 tiles: 1/8 of the CUs busy, so the
     # rate is set by one tile's latency; the all-gather of config 4 exists only at N > 1: --batch 2000 --gpus N)
     r2k = raw[:2000].contiguous()
-    for name, b in (("f16x2", blob_hx), ("f32", blob)):
+    for name, b in (("f16x2s", blob_hxs), ("f32", blob)):
         ms = time_kernel(lambda: ops.landmarks_to_pose(r2k, b, True), 200, warm=50)
-        ex[f"config4_2000_faces_step_{name}"] = {"ms_per_step": ms, "faces_per_sec": 2000 / ms * 1e3}
+        ex[f"config4_2000_faces_step_{name}"] = {"ms_per_step": ms, "faces_per_sec": 2000 / ms * 1e3, "timing": EV.format(n=200, w=50)}
     # the same step on the layer-per-launch path (same bits as the fused f16x2 kernel; what HIPPoseModel uses up to 4,096 faces)
-    ms = time_kernel(lambda: ops.landmarks_to_pose_small(r2k, blob_hx, True), 200, warm=50)
-    ex["config4_2000_faces_step_f16x2_layered"] = {"ms_per_step": ms, "faces_per_sec": 2000 / ms * 1e3}
+    ms = time_kernel(lambda: ops.landmarks_to_pose_small(r2k, blob_hxs, True), 200, warm=50)
+    ex["config4_2000_faces_step_f16x2s_layered"] = {"ms_per_step": ms, "faces_per_sec": 2000 / ms * 1e3, "timing": EV.format(n=200, w=50)}
     r64 = raw[:64].contiguous()
-    ms_f = time_kernel(lambda: ops.landmarks_to_pose(r64, blob_hx, True), 200, warm=50)
-    ms_l = time_kernel(lambda: ops.landmarks_to_pose_small(r64, blob_hx, True), 200, warm=50)
-    ex["tick_64_faces_f16x2"] = {"fused_ms": ms_f, "layered_ms": ms_l}
+    ms_f = time_kernel(lambda: ops.landmarks_to_pose(r64, blob_hxs, True), 200, warm=50)
+    ms_l = time_kernel(lambda: ops.landmarks_to_pose_small(r64, blob_hxs, True), 200, warm=50)
+    ex["tick_64_faces_f16x2s"] = {"fused_ms": ms_f, "layered_ms": ms_l, "timing": EV.format(n=200, w=50)}
     ms = time_kernel(lambda: ops.normalize_ipd(raw, True), 20)
     ex["k1_normalize"] = {"faces_per_sec": B / ms * 1e3, "gbs": B * BYTES_PER_FACE_K1 / ms / 1e6,
-                          "hbm_frac": B * BYTES_PER_FACE_K1 / ms / 1e6 / PEAK_HBM_GBS}
+                          "hbm_frac": B * BYTES_PER_FACE_K1 / ms / 1e6 / PEAK_HBM_GBS, "timing": EV.format(n=20, w=3)}
     art = weights.load_tucker_artefacts(os.path.join(ROOT, "outputs", "features"))
     cp = torch.from_numpy(np.stack([art["optimized_yaw"][:3], art["optimized_pitch"][:3], art["optimized_roll"][:3]])).to(dev)
     Wm = torch.from_numpy(art["W"].reshape(135, 1404)).to(dev)
@@ -553,7 +630,7 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     NL = 65536
     PL = torch.from_numpy(synth.tucker_params(NL, 5, seed=3)).to(dev)
     ms_l = time_stream(lambda: ops.tucker_objective(Wm, feats[:NL], PL, cp, order="fast"), 10)
-    ex["k3_tucker_objective_fast_order_65536"] = {"evals_per_sec": NL / ms_l * 1e3,
+    ex["k3_tucker_objective_fast_order_65536"] = {"evals_per_sec": NL / ms_l * 1e3, "timing": "10 launches back to back between one HIP event pair, 3 warm-ups",
                                        "f64_frac": NL * TUCKER_FLOP_PER_EVAL / ms_l / 1e9 / PEAK_F64_TFLOPS, "n": NL}
     # host-resident batch: pinned staging + copy stream overlapped with compute (PCIe-inclusive; never `value`)
     from nlml_hpe_amd.model import HIPPoseModel
@@ -565,7 +642,7 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     t0 = time.perf_counter()
     pipe.run(raw_host)
     dt = time.perf_counter() - t0
-    ex["host_resident_pcie_inclusive"] = {"faces_per_sec": B / dt, "gb_per_s_h2d": B * 5616 / dt / 1e9,
+    ex["host_resident_pcie_inclusive"] = {"faces_per_sec": B / dt, "gb_per_s_h2d": B * 5616 / dt / 1e9, "timing": "host wall clock around one run over the 65,536 faces, after a 32,768-face warm-up run",
                                           "note": "host numpy -> pinned -> H2D (copy stream) -> fused kernel -> D2H, double-buffered"}
     # BASELINE config 5 (per GPU): 64 concurrent streams, one tick = 64 raw-landmark sets -> smoothed pose + axes
     from nlml_hpe_amd.video import GraphedTick, VideoPoseTracker
@@ -589,7 +666,8 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
                 lat.append(time.perf_counter() - t0)
         lat = np.array(lat)
         ex[f"video_64_streams_{label}"] = {"tick_ms_p50": float(np.percentile(lat, 50) * 1e3), "tick_ms_p99": float(np.percentile(lat, 99) * 1e3),
-                                           "faces_per_sec_sustained": S / float(lat.mean()), "offered_load_faces_per_sec": 64 * 30}
+                                           "faces_per_sec_sustained": S / float(lat.mean()), "offered_load_faces_per_sec": 64 * 30,
+                                           "timing": "host wall clock per tick, synchronize on both sides, 300 ticks after 20"}
     # TD end-to-end (TD_Tester.Test): device-side lock-step Powell, one minimisation per face, BASELINE config 3 (4,096 faces).
     # The headline is the REFERENCE order (the default and the parity mode): the reference's objective bits, scipy's own
     # trajectory and end point (FX4 / FX5 bit-exact); the fast (matrix-core) order is reported beside it with how far its end
@@ -597,23 +675,26 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     idx = synth.tucker_grid_indices(4096, seed=2)
     Xg = torch.from_numpy(synth.tucker_grid_faces(art, idx, 1e-3, seed=2)).to(dev)
 
+    POWELL_RUNS = 3
+    POWELL_TIMING = ("mean of {n} launches, host wall clock around launch + synchronize (one launch is the whole workload), "
+                     "after a 64-face warm-up launch; min and max beside it").format(n=POWELL_RUNS)
+
     def powell(order):
         ops.tucker_powell(Wm, Xg[:64], cp, order=order)
         torch.cuda.synchronize()
-        best = None
-        for _ in range(2):               # one launch is the whole workload: two runs, the faster one is reported
+        dts = []
+        for _ in range(POWELL_RUNS):
             t0 = time.perf_counter()
             res = ops.tucker_powell(Wm, Xg, cp, order=order)
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-        return res, best
+            dts.append(time.perf_counter() - t0)
+        return res, float(np.mean(dts)), {"seconds_min": min(dts), "seconds_max": max(dts), "runs": POWELL_RUNS, "timing": POWELL_TIMING}
 
-    res_r, dt_r = powell("reference")
+    res_r, dt_r, spread_r = powell("reference")
     nfr = res_r["nfev"].double()
     ev_r = float(nfr.sum()) / dt_r
     ex["td_powell_end_to_end"] = {
-        "order": "reference (parity mode, the default)", "faces": int(Xg.shape[0]), "seconds": dt_r, "faces_per_sec": Xg.shape[0] / dt_r,
+        "order": "reference (parity mode, the default)", "faces": int(Xg.shape[0]), "seconds": dt_r, **spread_r, "faces_per_sec": Xg.shape[0] / dt_r,
         "mean_nfev": float(nfr.mean()), "max_nfev": float(nfr.max()), "face_evals_per_sec": ev_r,
         "converged_frac": float((res_r["status"] == 1).double().mean()),
         "roofline": {"bound": "valu_f64", "achieved": ev_r * TUCKER_REF_OPS_PER_EVAL / 1e12, "peak": PEAK_F64_VALU_TOPS, "unit": "T op/s",
@@ -622,11 +703,11 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
                      "kernel": "tucker_powell_kernel<NLML_TD_ORDER_REFERENCE>", "kernel_ms": dt_r * 1e3,
                      "note": "947,700 separately rounded f64 vector operations per evaluation against the f64 vector issue rate "
                              "(non-fma); the launch lasts as long as its slowest face"}}
-    res, dt = powell("fast")
+    res, dt, spread_f = powell("fast")
     nf = res["nfev"].double()
     dd = torch.rad2deg((res_r["x"][:, :3] - res["x"][:, :3]).abs()).max(dim=1).values
     ex["td_powell_fast_order"] = {
-        "order": "fast (f64 matrix cores; opt-in, NOT a parity mode)", "faces": int(Xg.shape[0]), "seconds": dt, "faces_per_sec": Xg.shape[0] / dt,
+        "order": "fast (f64 matrix cores; opt-in, NOT a parity mode)", "faces": int(Xg.shape[0]), "seconds": dt, **spread_f, "faces_per_sec": Xg.shape[0] / dt,
         "mean_nfev": float(nf.mean()), "max_nfev": float(nf.max()), "face_evals_per_sec": float(nf.sum()) / dt,
         "converged_frac": float((res["status"] == 1).double().mean()),
         "end_point_vs_reference_order": {"median_deg": float(dd.median()), "max_deg": float(dd.max()),

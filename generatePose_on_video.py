@@ -108,7 +108,7 @@ if __name__ == "__main__":
     parser.add_argument("--output_path", type=str)
     parser.add_argument("--device", default="cuda:0")
     parser.add_argument("--mode", choices=["f16x2", "f16x2s", "f32", "bf16"], default=None,
-                        help="kernel mode (default: NLML_HPE_MODE or f16x2 = fast; f16x2s = strict-fast; f32 = strict parity; bf16 = throughput only)")
+                        help="kernel mode (default: NLML_HPE_MODE or f16x2s = strict-fast; f32 = strict parity; f16x2 = opt-in, 1.10x the reference's error; bf16 = throughput only)")
     args = parser.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world > 1:                                             # one rank per GPU; RCCL ("nccl") unless rehearsing on one GPU

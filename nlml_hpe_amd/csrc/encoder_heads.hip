@@ -707,6 +707,9 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
         if (g.live1) a.valid[row0 + g.srow + 32] = ((m1 >> sh) & 0xFFull) ? 1 : 0;
       }
     }
+    // the pieces parked after pass B are dead, but another wave may still be WRITING its own: H2 overwrites that region, so
+    // every wave's park stores must be behind this barrier before any wave stores H2 (write-after-write across waves)
+    __syncthreads();
     job_store<4, NFB, ACT_RELU>(c, acc1, lds + O_H2, S_H2, 128 * wv, 0);
   }
   __syncthreads();

@@ -98,7 +98,7 @@ __device__ __forceinline__ double uniform_f64(double v) {
 }
 
 // Evaluations of machine slots (slots >> 4n) & 15, n < NE (f-vectors in sh.fvec[slot], parameters par(slot, k)) against the rows
-// xrow(slot); results into rs.err[slot] (and x_hat rows where xhrow(slot) != nullptr).  All 512 threads; barriers inside.
+// xrow(slot); results into rs.err[slot] (and x_hat rows where xhrow(slot) != nullptr).  All TR_NT (768) threads; barriers inside.
 // par / xrow / xhrow are small structs passed BY VALUE (a reference into the caller's frame would be scratch memory here).
 //
 // BALANCED passes (NE >= TR_BAL_FROM): with thread t on columns t and t + 768 the 22 wave-columns (1404 / 64) fall 6 / 6 / 5 / 5 on
@@ -130,9 +130,10 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
 #endif
   TRS(0);
   // Wm as a buffer resource: a load is (scalar row offset) + (the lane's column offset in a vector register), so the ring costs no
-  // address arithmetic on the vector ALUs, and reads beyond the 135 rows (dead lanes of the last row, the two prefetches past the
-  // last block) return 0 without touching memory.  Arguments of a non-inlined function arrive in vector registers: the base is
-  // made uniform first.
+  // address arithmetic on the vector ALUs.  Every load stays INSIDE Wm by construction, not by the descriptor's range check (the
+  // scalar offset is not part of that check): the two prefetches past the last block re-read row 134 (scalar min), and a dead
+  // lane (column >= 1404) reads column 0 of its row; neither value is used.  Arguments of a non-inlined function arrive in vector
+  // registers: the base is made uniform first.
   const float* Wm = reinterpret_cast<const float*>(
       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)Wm_ >> 32)) << 32) |
       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)Wm_));
@@ -160,12 +161,17 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
   // from LDS with every block is 7 % slower; holding f_p for all three k in registers spills at the 168 registers that three
   // waves per SIMD allow.)  f_p is read at the top of its block, u and f_y when their loop level advances.
   float wr[3][3][TR_COLS];
+  unsigned voff[TR_COLS];
+#pragma unroll
+  for (int c = 0; c < TR_COLS; ++c) voff[c] = livec[c] ? mc[c] * 4 : 0u;
   auto wload = [&](int b, float (&dst)[3][TR_COLS]) {
 #pragma unroll
-    for (int l = 0; l < 3; ++l)
+    for (int l = 0; l < 3; ++l) {
+      const int row = 3 * b + l < TQ ? 3 * b + l : TQ - 1;
 #pragma unroll
       for (int c = 0; c < TR_COLS; ++c)
-        dst[l][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, mc[c] * 4, (3 * b + l) * (TM * 4), 0));
+        dst[l][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, voff[c], row * (TM * 4), 0));
+    }
   };
   // the pass's factors -> rs.fac[n][0..4] = u, [5..7] = f_y, [8..10] = f_p, [11..13] = f_r.  Their loads are issued first, the
   // first two blocks of the ring next (memory loads return in order), so the ring's latency overlaps the table and its barrier
@@ -307,7 +313,9 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
 #pragma unroll
   for (int n = 0; n < NE; ++n) {
     const int slot = (slots >> (4 * n)) & 15;
+#ifdef TR_NO_XPREFETCH
     const float* xr = xrow(slot);
+#endif
 #ifdef TR_STAMPS
     double* xh = nullptr;
 #else

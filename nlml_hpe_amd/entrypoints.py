@@ -10,7 +10,7 @@ import warnings
 import numpy as np
 import yaml
 
-from . import synth
+from . import _lib, synth
 from .model import HIPPoseModel, load_model
 
 
@@ -23,9 +23,9 @@ def resolve_model(device, scripted_name: str = "models/combined_model_scripted.p
                   input_size: int | None = None, synthetic_seed: int | None = 0, mode=None) -> HIPPoseModel:
     """The scripted file the reference loads if present; else the per-network state dicts; the encoder
     falls back to SYNTHETIC weights (with a warning) because the reference ships no models/Encoder.pth.
-    mode: "f16x2" (default), "f16x2s", "f32" or "bf16" (model.HIPPoseModel); the NLML_HPE_MODE environment variable
+    mode: "f16x2s" (default: strict-fast), "f32", "f16x2" (opt-in, 1.10x the reference's error) or "bf16" (model.HIPPoseModel); the NLML_HPE_MODE environment variable
     sets it for the entry-point scripts without touching their command lines."""
-    mode = mode if mode is not None else os.environ.get("NLML_HPE_MODE", "f16x2")
+    mode = mode if mode is not None else os.environ.get("NLML_HPE_MODE", _lib.DEFAULT_MODE_NAME)
     if os.path.isfile(scripted_name):
         return load_model(scripted_name, device, mode=mode)
     try:

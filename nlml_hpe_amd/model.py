@@ -18,18 +18,17 @@ from . import _lib, ops, weights
 class HIPPoseModel:
     """CombinedAnglePredictionModel (Model_Builder.py:107-126) on the fused gfx950 kernel."""
 
-    def __init__(self, encoder_sd: dict, head_sds: dict, device="cuda", mode=_lib.MODE_F16X2):
+    def __init__(self, encoder_sd: dict, head_sds: dict, device="cuda", mode=_lib.DEFAULT_MODE):
         """mode (int constant or name):
-          _lib.MODE_F16X2 "f16x2"  (default) the fast mode, on the f16 matrix cores: every f32 operand as two f16 pieces; ~1e-5 deg
-                                   from the reference on small poses, and at the reference's operating range (poses to
-                                   +-60 deg, FX3c) 1.86e-5 / 5.9e-5 / 1.22e-4 deg from the exact result in p50 / p99 / max =
-                                   1.10 / 1.08 / 1.24x the reference's own distance, 0.024 % of the faces beyond 1e-4 deg; 3x the faces/s
-                                   of the f32 mode; a face whose activations leave f16's range is re-evaluated in f32 inside
-                                   the same launch (no input-range limit; ~40x slower if EVERY face does);
-          _lib.MODE_F16X2S "f16x2s" the strict-fast mode: f16x2's operands and matrix instructions, the small products of
-                                   each K step in accumulators of their own (layers 0 to 2): at the operating range no farther
-                                   from the exact result than the reference itself, at ~0.78x f16x2's faces/s; same range
-                                   behaviour as f16x2;
+          _lib.MODE_F16X2S "f16x2s" (DEFAULT) the strict-fast mode, on the f16 matrix cores: every f32 operand as two f16 pieces,
+                                   the small products of each K step in accumulators of their own (layers 0 to 2): at the
+                                   reference's operating range (poses to +-60 deg, FX3c) no farther from the exact result than
+                                   the reference's own f32 forward in p50 / p99 / max; a face whose activations leave f16's
+                                   range is re-evaluated in f32 inside the same launch (no input-range limit);
+          _lib.MODE_F16X2 "f16x2"  OPT-IN fast mode, 1.10x THE REFERENCE'S ERROR: the same operands on single accumulators
+                                   where registers are short: 1.86e-5 / 5.9e-5 / 1.22e-4 deg from the exact result in
+                                   p50 / p99 / max at the operating range = 1.10 / 1.08 / 1.24x the reference's own distance,
+                                   0.024 % of the faces beyond 1e-4 deg; same range behaviour as f16x2s;
           _lib.MODE_F32   "f32"    the strict parity mode, on the f32 matrix cores: layers 0 to 3 summed in blocks of
                                    128 k, bit-identical to the C oracle's order 2; at the operating range 1.25e-5 / 4.0e-5 /
                                    8.7e-5 deg from the exact result -- no further out than the reference itself; no range limit;
@@ -99,7 +98,7 @@ class HIPPoseModel:
 
 
 def load_model(path_or_dir: str = "models", device=None, encoder_state_dict: dict | None = None,
-               mode=_lib.MODE_F16X2) -> HIPPoseModel:
+               mode=_lib.DEFAULT_MODE) -> HIPPoseModel:
     """Build the HIP model from the reference's artefact layout.
 
     path_or_dir: a TorchScript file saved by NLML_HPE_Model_Builder.py (:222-223), or a directory holding

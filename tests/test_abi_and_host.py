@@ -158,7 +158,10 @@ def test_mode_names_and_default_are_the_parity_modes():
         assert len(set(sizes)) == 4 and all(sizes), (F, sizes)
         assert sizes[3] == sizes[2] + 256
     default = inspect.signature(M.HIPPoseModel.__init__).parameters["mode"].default
-    assert default in (_lib.MODE_F16X2, _lib.MODE_F32), "the default must be one of the two parity modes, never bf16"
+    assert default == _lib.DEFAULT_MODE and default in (_lib.MODE_F16X2S, _lib.MODE_F32), \
+        "the default must be a STRICT parity mode (inside the reference's own error): never f16x2 (1.10x), never bf16"
+    assert inspect.signature(M.load_model).parameters["mode"].default == _lib.DEFAULT_MODE
+    assert _lib.mode_from_name(_lib.DEFAULT_MODE_NAME) == _lib.DEFAULT_MODE
     with pytest.raises(_lib.NlmlError):
         M.HIPPoseModel(synth.encoder_state_dict(136, 0), weights.load_head_state_dicts("models"), device="cpu")
 

@@ -963,11 +963,15 @@ def test_fx3c_no_worse_than_the_reference_itself(mode, head_sds, golden_dir, dev
     r = fixture_models.error_stats(g["rad"], truth)
     r1 = fixture_models.error_stats(g["rad_b1"], truth)
     vs_ref = fixture_models.error_stats(out, g["rad"])
+    vs_b1 = fixture_models.error_stats(out, g["rad_b1"])       # the reference's REAL call shape: one face per call (NLML_HPE_Test.py:262-272)
     ref_self = fixture_models.error_stats(g["rad_b1"], g["rad"])
     _report(f"fx3c_{mode}", kernel_p50=k["p50"], kernel_p99=k["p99"], kernel_max=k["max"], kernel_frac_above=k["frac_above_1e-4"],
             ref_p50=r["p50"], ref_p99=r["p99"], ref_max=r["max"], ref_frac_above=r["frac_above_1e-4"],
             ref_batch1_p50=r1["p50"], ref_batch1_p99=r1["p99"], ref_batch1_max=r1["max"],
             kernel_vs_ref_max=vs_ref["max"], kernel_vs_ref_frac_above=vs_ref["frac_above_1e-4"],
+            kernel_vs_ref_p50=vs_ref["p50"], kernel_vs_ref_p99=vs_ref["p99"],
+            kernel_vs_batch1_p50=vs_b1["p50"], kernel_vs_batch1_p99=vs_b1["p99"], kernel_vs_batch1_max=vs_b1["max"],
+            kernel_vs_batch1_frac_above=vs_b1["frac_above_1e-4"],
             ref_batch1_vs_batched_max=ref_self["max"], ref_batch1_vs_batched_frac_above=ref_self["frac_above_1e-4"])
     # f32 kernel (layers 0 to 3 summed in blocks of 128 k): no worse than the reference in every statistic, nothing beyond 1e-4 deg.
     # split-f16 kernel (the fast mode): 1.10 / 1.08 / 1.24x the reference's distance from the truth in p50 / p99 / max (measured: 1.86e-5 /
@@ -1302,14 +1306,18 @@ def test_reference_order_objective_on_200k_random_evaluations(tucker_art, device
     assert bad <= 1, bad      # (0 measured; 1 allowed for a cos value where libm is not correctly rounded AND the f32 rounding flips)
 
 
-@pytest.mark.parametrize("mode", ["f16x2", "f16x2s"])
+@pytest.mark.parametrize("mode", [None, "f32", "f16x2"])
 def test_bench_line_carries_the_contract_fields(mode, repo_root, device):
     """`python bench.py` (short run): ONE JSON line with the contract's fields, a roofline block, the CPU baseline with both live parity
-    checks -- the seed-0 sample of the timed batch and the operating-range statistics (FX3c) next to the reference's own."""
+    checks -- the seed-0 sample of the timed batch and the operating-range statistics (FX3c) next to the reference's own.  mode None =
+    no --mode flag: the default must be the strict-fast mode, and that run also measures roofline.traffic live (two rocprofv3 --pmc
+    child passes on this box); the other modes run with --no-traffic and must say `traffic: null`, never a number from elsewhere."""
     import subprocess
     import sys
+    flags = ["--no-traffic", "--mode", mode] if mode else []
+    mode = mode or "f16x2s"
     res = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--steps", "3", "--warmup", "1", "--settle-ms", "0",
-                          "--no-extra", "--cpu-seconds", "1", "--mode", mode], capture_output=True, text=True, timeout=600, cwd=repo_root)
+                          "--no-extra", "--cpu-seconds", "1"] + flags, capture_output=True, text=True, timeout=900, cwd=repo_root)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -1319,14 +1327,21 @@ def test_bench_line_carries_the_contract_fields(mode, repo_root, device):
         assert k in rec, k
     assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["value"] > 1e6 and "workload" in rec["config"]
     rf = rec["roofline"]
-    assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["traffic"]
+    assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rec["dtype"] == mode
+    assert rec["warmup"] == 1 and rec["warmup_effective"] == 1      # --settle-ms 0: --warmup is the only warm-up
+    if flags:
+        assert rf["traffic"] is None and "not measured" in rf["traffic_source"]
+    else:   # measured on this box in this run: at least the algorithmic bytes (65,536 x 5,628 B), at most a few times that
+        assert rf["traffic"] is not None, rf["traffic_source"]
+        assert 0.9 * 65536 * 5628 <= rf["traffic"] <= 8 * 65536 * 5628 and "measured in this run" in rf["traffic_source"]
     cb = rec["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert cb["parity_check"]["max_abs_deg_vs_f64_oracle"] <= POSE_TOL_DEG
     rng = cb["parity_check_operating_range"]
     k_, r_ = rng["kernel_vs_f64_truth"], rng["reference_batched_vs_f64_truth"]
     assert rng["faces"] == 16384 and rng["mode"] == mode and rec["config"]["mode"] == mode
-    if mode == "f16x2s":    # the strict-fast mode: inside the reference's own distance from the truth
+    assert "kernel_vs_reference_batch1" in rng and "kernel_vs_reference_batched" in rng
+    if mode in ("f16x2s", "f32"):    # the strict modes: inside the reference's own distance from the truth
         assert k_["p50_deg"] <= 1.05 * r_["p50_deg"] and k_["max_deg"] <= POSE_TOL_DEG and k_["frac_above_1e-4_deg"] == 0.0
     else:
         assert k_["p50_deg"] <= 1.32 * r_["p50_deg"] and k_["max_deg"] <= 1.47e-4
