@@ -982,6 +982,16 @@ def test_fx3c_no_worse_than_the_reference_itself(mode, head_sds, golden_dir, dev
     ratio = {"f32": (1.05, 1.05, 1.05), "f16x2s": (1.05, 1.05, 1.05), "f16x2": (1.32, 1.30, 1.49)}[mode]
     for s_, q_ in zip(("p50", "p99", "max"), ratio):
         assert k[s_] <= q_ * r[s_], (mode, s_, k, r)
+    # Against the reference's REAL call shape (one face per call, NLML_HPE_Test.py:262-272; its results are 9.2e-6 deg p50 from the
+    # truth, closer than its batched call's 1.69e-5): measured p50 / p99 / max / fraction beyond 1e-4 deg -- f16x2s 1.77e-5 / 5.52e-5 /
+    # 9.65e-5 / 0, f32 1.54e-5 / 4.70e-5 / 8.54e-5 / 0, f16x2 (opt-in) 2.05e-5 / 6.57e-5 / 1.35e-4 / 0.043 %.  Bounds = measured + 20 %
+    # (the fraction: + 2 faces).  For comparison the reference's batched call against its own one-face calls: 1.88e-5 / 6.06e-5 / 1.23e-4 / 0.012 %.
+    b1_bound = {"f16x2s": (2.13e-5, 6.63e-5, 1.16e-4, 2.0 / len(x)), "f32": (1.85e-5, 5.64e-5, 1.03e-4, 2.0 / len(x)),
+                "f16x2": (2.46e-5, 7.89e-5, 1.63e-4, 5.2e-4)}[mode]
+    for s_, q_ in zip(("p50", "p99", "max", "frac_above_1e-4"), b1_bound):
+        assert vs_b1[s_] <= q_, (mode, s_, vs_b1)
+    if mode != "f16x2":   # the strict modes are closer to the reference's one-face results than its own batched call is
+        assert vs_b1["p50"] <= ref_self["p50"] and vs_b1["max"] <= ref_self["max"], (vs_b1, ref_self)
     if mode == "f16x2s":
         # nothing beyond 1e-4 deg of the truth.  Against the reference's batched output: two evaluations with INDEPENDENT errors of
         # 1.5e-5 and 1.7e-5 deg p50 -- 0.073 % of the faces differ by more than 1e-4 deg, max 1.34e-4 deg (measured; bounds +20 %).
