@@ -26,6 +26,9 @@ int launch_encoder_heads_bf16(const float* x, int64_t ldx, const float* raw, int
 int launch_encoder_heads_f16x2(const float* x, int64_t ldx, const float* raw, int normalize,
                                int64_t B, int F, const void* blob, float* out, float* latent,
                                uint8_t* valid, int split, void* stream);   // split: NLML_MODE_F16X2S
+// encoder_heads_f16x2_w8.hip (NLML_MODE_F16X2S, eight waves per workgroup: the strict-fast mode's fused kernel)
+int launch_encoder_heads_f16x2_w8(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,
+                                  const void* blob, float* out, float* latent, uint8_t* valid, void* stream);
 // encoder_heads_f16x2_small.hip (split-f16 mode, big layers as separate launches + one tail launch, for small batches)
 size_t small_workspace_bytes(int64_t B, int F);
 int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,

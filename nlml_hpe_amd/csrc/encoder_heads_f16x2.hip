@@ -27,6 +27,8 @@
 // fetches ride in the previous stage's epilogue; the heads run one at a time over both face blocks (encoder_heads_f16x2_dev.h).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/nlml_hpe.h"
 #include "abi_internal.h"
 #include "encoder_heads_f16x2_dev.h"
@@ -612,6 +614,10 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
 int launch_encoder_heads_f16x2(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,
                                const void* blob, float* out, float* latent, uint8_t* valid, int split, void* stream) {
   if (B == 0) return 0;
+  // the strict-fast mode's production kernel has eight waves per workgroup (encoder_heads_f16x2_w8.hip; same bits); the four-wave
+  // instantiation below stays reachable for A/B timing: NLML_K2_STRICT_W4=1
+  static const bool strict_w4 = [] { const char* e = getenv("NLML_K2_STRICT_W4"); return e && e[0] == '1'; }();
+  if (split && !strict_w4) return launch_encoder_heads_f16x2_w8(x, ldx, raw, normalize, B, F, blob, out, latent, valid, stream);
   hx::Args a;
   a.B = B; a.F = F; a.blob = blob; a.out = out; a.latent = latent; a.valid = valid; a.norm = 0;
   if (raw) {

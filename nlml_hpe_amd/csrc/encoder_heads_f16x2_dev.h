@@ -147,7 +147,10 @@ __device__ __forceinline__ void step_fine(f32x16 (&acc)[NB][NFB], f32x16 (&accS)
 // issue time of ~40 loads each -- while the LDS reads and the MFMAs (kloop_run) wait for the barrier.
 constexpr int ring_slots(int nb, int nfb) { return (nb * nfb >= 4) ? 4 : 6; }
 
-template <int NB, int NFB, int K16>
+// WSTEP: fragments (16-byte units per lane, i.e. h8 elements / 64 lanes) between consecutive K steps of the stream `w` points into.
+// The default is a job's own stream (NB blocks x 2 pieces); a wave that takes only NB of a job's blocks (the eight-wave kernel:
+// two of four, one of two) passes the job's full stride and a `w` that points at its first block.
+template <int NB, int NFB, int K16, int WSTEP = NB * 2 * 64>
 __device__ __forceinline__ void kloop_pro(h8 (&wr)[ring_slots(NB, NFB)][NB][2], const h8* __restrict__ w) {
   constexpr int R = ring_slots(NB, NFB), D = R - 1;
 #pragma unroll
@@ -156,12 +159,12 @@ __device__ __forceinline__ void kloop_pro(h8 (&wr)[ring_slots(NB, NFB)][NB][2], 
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) wr[d][nb][p] = w[((d * NB + nb) * 2 + p) * 64];
+        for (int p = 0; p < 2; ++p) wr[d][nb][p] = w[d * WSTEP + (nb * 2 + p) * 64];
     }
   }
 }
 
-template <int NB, int NFB, int K16>
+template <int NB, int NFB, int K16, int WSTEP = NB * 2 * 64>
 __device__ __forceinline__ void kloop_run(f32x16 (&acc)[NB][NFB], f32x16 (&accS)[NB][NFB], h8 (&wr)[ring_slots(NB, NFB)][NB][2],
                                           const h8* __restrict__ w, const char* in, int plane, int fb_stride) {
   constexpr int R = ring_slots(NB, NFB), D = R - 1;
@@ -172,7 +175,7 @@ __device__ __forceinline__ void kloop_run(f32x16 (&acc)[NB][NFB], f32x16 (&accS)
     for (int p = 0; p < 2; ++p) xr[0][fb][p] = *reinterpret_cast<const h8*>(in + p * plane + fb * fb_stride);
   auto step = [&](int r, int xs, int sp, int sx, bool prefetch) {
     const int sxc = sx < K16 ? sx : K16 - 1;
-    step_fine<NB, NFB>(acc, accS, wr[r], xr[xs], wr[(r + D) % R], w + (size_t)sp * (NB * 2 * 64), prefetch,
+    step_fine<NB, NFB>(acc, accS, wr[r], xr[xs], wr[(r + D) % R], w + (size_t)sp * WSTEP, prefetch,
                        [&](int fb, int p) { xr[xs ^ 1][fb][p] = *reinterpret_cast<const h8*>(in + p * plane + fb * fb_stride + 32 * sxc); },
                        [](int) {});
   };
@@ -187,12 +190,12 @@ __device__ __forceinline__ void kloop_run(f32x16 (&acc)[NB][NFB], f32x16 (&accS)
   for (int r = 0; r < TAIL; ++r) step(r, r & 1, 0, GROUPS * R + r + 1, false);
 }
 
-template <int NB, int NFB, int K16>
+template <int NB, int NFB, int K16, int WSTEP = NB * 2 * 64>
 __device__ __forceinline__ void kloop(f32x16 (&acc)[NB][NFB], f32x16 (&accS)[NB][NFB], const h8* __restrict__ w, const char* in,
                                       int plane, int fb_stride) {
   h8 wr[ring_slots(NB, NFB)][NB][2];
-  kloop_pro<NB, NFB, K16>(wr, w);
-  kloop_run<NB, NFB, K16>(acc, accS, wr, w, in, plane, fb_stride);
+  kloop_pro<NB, NFB, K16, WSTEP>(wr, w);
+  kloop_run<NB, NFB, K16, WSTEP>(acc, accS, wr, w, in, plane, fb_stride);
 }
 
 // small accumulator helpers
