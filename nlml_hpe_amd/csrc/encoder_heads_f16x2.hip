@@ -616,7 +616,8 @@ int launch_encoder_heads_f16x2(const float* x, int64_t ldx, const float* raw, in
   if (B == 0) return 0;
   // the strict-fast mode's production kernel has eight waves per workgroup (encoder_heads_f16x2_w8.hip; same bits); the four-wave
   // instantiation below stays reachable for A/B timing: NLML_K2_STRICT_W4=1
-  static const bool strict_w4 = [] { const char* e = getenv("NLML_K2_STRICT_W4"); return e && e[0] == '1'; }();
+  const char* const w4env = getenv("NLML_K2_STRICT_W4");   // read per call: a test flips it inside one process
+  const bool strict_w4 = w4env && w4env[0] == '1';
   if (split && !strict_w4) return launch_encoder_heads_f16x2_w8(x, ldx, raw, normalize, B, F, blob, out, latent, valid, stream);
   hx::Args a;
   a.B = B; a.F = F; a.blob = blob; a.out = out; a.latent = latent; a.valid = valid; a.norm = 0;

@@ -106,12 +106,23 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
     nzbits |= (__float_as_uint(st.v[2 * j]) | __float_as_uint(st.v[2 * j + 1])) & m;
     split2(st.v[2 * j], st.v[2 * j + 1], pend_hi[j], pend_lo[j]);
   };
-  auto lw_store = [&](int buf_off, int piece) {
-    char* d = c.lds + O_XS + buf_off + (srow * S_XS + scol) * 2;
+  // x slabs of this kernel: 32 columns = 64 bytes per row and plane, NO padding, the 16-byte chunk c of row r stored at chunk
+  // c ^ ((r >> 2) & 3): the 16 lanes of a ds_read_b128 group (rows distinct mod 16, one logical chunk) then cover all sixteen
+  // 16-byte slots of the 256-byte bank row -- conflict-free without the pad.  Four slabs (2 x 32 KB... 4 x 8 KB) sit in the LAST
+  // 32 KB of LDS, so that the parked layer-1 accumulators (128 KB from offset 0) and the slabs live side by side; the 2 KB by which
+  // the h1 / h2 images reach into that range are never live together with a slab (barriers on both sides of every layer-0 pass).
+  // The slabs form TWO buffers of 64 columns: an iteration of the main loop reads one (four K steps) while the other is being
+  // written for the next iteration -- ONE barrier per four K steps instead of per two (the slab barrier cost 14-16 k of a pass's
+  // 96-109 k cycles: every wave waits for the slowest of eight each time; -DW8_ABL_NOBAR stamps).
+  constexpr int XW_PLANE = 64 * 64, XW_SLAB = 2 * XW_PLANE, XW_BUF = 2 * XW_SLAB, O_XW = LDS_BYTES - 2 * XW_BUF;
+  static_assert(O_XW >= 16 * 512 * 16, "slabs behind the parked accumulators");
+  const int wr_off = srow * 64 + ((((tid & 7) >> 1) ^ ((srow >> 2) & 3)) << 4) + 8 * (tid & 1);   // this thread's 8 bytes of a plane
+  auto lw_store = [&](int slab_off, int piece) {
+    char* d = c.lds + O_XW + slab_off + wr_off;
     if (piece == 0) *reinterpret_cast<u2*>(d) = u2{pend_hi[0], pend_hi[1]};
-    else *reinterpret_cast<u2*>(d + P_XS) = u2{pend_lo[0], pend_lo[1]};
+    else *reinterpret_cast<u2*>(d + XW_PLANE) = u2{pend_lo[0], pend_lo[1]};
   };
-  auto lwrite = [&](int buf_off, Set& st, bool real_slab) {
+  auto lwrite = [&](int slab_off, Set& st, bool real_slab) {
     lw_begin(st);
     if (NORM) {
 #pragma unroll
@@ -120,27 +131,36 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) lw_split(st, j, real_slab);
-    lw_store(buf_off, 0);
-    lw_store(buf_off, 1);
+    lw_store(slab_off, 0);
+    lw_store(slab_off, 1);
   };
 
   const int job = 4 * pass + jw;
   load_bias<NB, NFB>(acc, c.blob4 + c.hdr.b_off(ST_E0) + job * (4 * 8) + (2 * nbh) * 8, c.h);
   zero_acc<NB, NFB>(accS);
   const h8* w = c.blob8 + c.hdr.w_off(ST_E0) + (size_t)job * c.hdr.job_w16(ST_E0) + (2 * nbh * 2) * 64 + c.lane;
+#ifdef W8_ABL_WHOT   // timing-only ablation (wrong results): every K step reads the weights of steps 0..3 -- always L2-resident, all CUs the same lines
+  auto wfrag = [&](int ks) { return w + (size_t)(ks & 3) * WSTEP; };
+#elif defined(W8_ABL_WL2)   // timing-only ablation (wrong results): a small L2-resident region per CU (no shared hot lines)
+  auto wfrag = [&](int ks) { return w + (size_t)((ks & 3) + 4 * (blockIdx.x % 20)) * WSTEP; };
+#else
   auto wfrag = [&](int ks) { return w + (size_t)ks * WSTEP; };   // K step ks of this wave's two blocks
+#endif
 
-  // TWO staging register sets (4 floats per thread each), one per slab parity: slab s+2 is written to LDS during slab s from
-  // set[s & 1], which is refilled at once with the loads of slab s+4 (vmcnt counts in issue order: see encoder_heads_f16x2.hip)
+  // TWO staging register sets (4 floats per thread each), slab q in set[q & 1]: a slab's global loads are issued one iteration (four K
+  // steps) before it is written to LDS.  (Four sets -- loads two iterations ahead, for pass 0's x from HBM -- are eight more registers,
+  // and at 256 per wave those spill into the K loops.)  vmcnt counts in issue order: encoder_heads_f16x2.hip.
   Set set[2];
-  constexpr int R0 = 4, D0 = R0 - 1;   // weight ring: K step ks in slot ks % 4 = 2 * (slab & 1) + step of the slab
-  static_assert(2 * XS_STEPS == R0, "two slabs == ring slots");
+#ifndef W8_RING
+#define W8_RING 4
+#endif
+  constexpr int R0 = W8_RING, D0 = R0 - 1;   // weight ring (4: K step ks in slot ks % 4 = its step within the iteration)
   h8 wr[R0][NB][2];
   gload(0, set[0]);
   gload(1, set[1]);
   lwrite(0, set[0], true);
+  lwrite(XW_SLAB, set[1], true);
   gload(2, set[0]);
-  lwrite(SLAB_BYTES, set[1], true);
   gload(3, set[1]);
 #pragma unroll
   for (int d = 0; d < D0; ++d)
@@ -150,54 +170,87 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
       for (int pp = 0; pp < 2; ++pp) wr[d][nb][pp] = wfrag(d)[(nb * 2 + pp) * 64];
   __syncthreads();
 
-  const int lane_off = (c.f * S_XS + 8 * c.h) * 2;   // bytes
-  constexpr int FB = 32 * S_XS * 2;                  // face block stride inside a plane
+  // reader: lane (f, h) of face block fb reads row 32*fb + f, logical chunk 2*(step & 1) + h of slab (step >> 1): two lane
+  // addresses per buffer (step parity 0 / 1), formed once per iteration; everything else is an immediate offset
+  const int rd0 = c.f * 64 + ((c.h ^ ((c.f >> 2) & 3)) << 4);
+  typedef __attribute__((address_space(3))) const char LdsC;   // (address space 3 kept through the opaque copies below: ds_read, not flat_load)
+  LdsC* const xb0 = (LdsC*)(c.lds + O_XW + rd0);
+  LdsC* const xb1 = (LdsC*)(c.lds + O_XW + (rd0 ^ 32));
   h8 xr[2][NFB][2];
+  auto xread = [&](LdsC* base, int t, int fb, int pp) {     // x operand (fb, piece pp) of step t (0..3) of a buffer
+    return *reinterpret_cast<const __attribute__((address_space(3))) h8*>(base + (t >> 1) * XW_SLAB + pp * XW_PLANE + fb * (32 * 64));
+  };
+  const int niter = nslab / 2;
 #pragma unroll
   for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) xr[0][fb][pp] = *reinterpret_cast<const h8*>(c.lds + O_XS + lane_off + pp * P_XS + fb * FB);
-
-  int o0 = 0, o1 = SLAB_BYTES, o2 = 2 * SLAB_BYTES;   // buffers of slabs s, s+1, s+2
-  auto slab = [&](int s, auto par_c) {
-    constexpr int PAR = decltype(par_c)::value;
-    const char* xrow = c.lds + O_XS + o0 + lane_off;
-    const char* xnext = c.lds + O_XS + o1 + lane_off;
-    const bool real = s + 2 < nslab;
+    for (int pp = 0; pp < 2; ++pp) xr[0][fb][pp] = xread(xb0, 0, fb, pp);
+  int cur = 0, nxt = XW_BUF;   // byte offsets of the buffer being read / written
+  for (int it = 0; it < niter; ++it) {
+    const int s = 2 * it;
+    LdsC* xc[2] = {xb0 + cur, xb1 + cur};   // this iteration's buffer, step parity 0 / 1
+    LdsC* xn = xb0 + nxt;                   // the next iteration's first step
+    asm volatile("" : "+v"(xc[0]), "+v"(xc[1]), "+v"(xn));   // (formed here, not again in front of every read)
 #pragma unroll
-    for (int kk = 0; kk < XS_STEPS; ++kk) {
-      const int slot = 2 * PAR + kk;                        // == K step % 4: two slabs are exactly one turn of the ring
-      const int ks = s * XS_STEPS + kk;
-      step_fine<NB, NFB>(acc, accS, wr[slot], xr[kk & 1], wr[(slot + D0) % R0], wfrag(ks + D0), true,
+    for (int t = 0; t < 4; ++t) {
+      const int ks = 4 * it + t;
+      // The iteration's ONE barrier stands before step 3: by then the buffer being written is complete (slab s+2 is staged during
+      // step 0, slab s+3 during step 1) and the buffer being read has been read to its end (step 3's operands were fetched during
+      // step 2) -- so step 3 fetches the next iteration's first operands from the new buffer under its own MFMAs, and the next
+      // iteration may overwrite the old one from its first slot on.
+#ifndef W8_ABL_NOBAR
+      if (t == 3) __syncthreads();
+#endif
+#ifdef W8_ALTPRIO   // experiment: the two waves of a SIMD take turns at the higher priority, step by step
+      if (((c.wv >> 2) ^ t) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+      step_fine<NB, NFB>(acc, accS, wr[t], xr[t & 1], wr[(t + D0) % R0], wfrag(ks + D0), true,
               [&](int fb, int pp) {                         // the next K step's x operands
-                xr[(kk + 1) & 1][fb][pp] = (kk + 1 < XS_STEPS)
-                                               ? *reinterpret_cast<const h8*>(xrow + pp * P_XS + fb * FB + 32 * (kk + 1))
-                                               : *reinterpret_cast<const h8*>(xnext + pp * P_XS + fb * FB);
+                xr[(t + 1) & 1][fb][pp] = t < 3 ? xread(xc[(t + 1) & 1], t + 1, fb, pp) : xread(xn, 0, fb, pp);
               },
-              [&](int m) {   // slab s+2's staging, one piece behind each of the slab's 24 MFMAs
-                const int j = 12 * kk + m;
-                if (j == 0) lw_begin(set[PAR]);
-                if (NORM && j < 12) lw_norm2(set[PAR], j / 6, j % 6);
-                if (NORM && j == 12) lw_rotate();
-                if (j == 13 || j == 14) lw_split(set[PAR], j - 13, real);
-                if (j == 15) lw_store(o2, 0);
-                if (j == 16) lw_store(o2, 1);
-                if (j == 17) gload(s + 4, set[PAR]);
+              [&](int m) {   // the staging of slab s+2 (step 0) and s+3 (step 1), one piece behind an MFMA
+#ifdef W8_ABL_NOSTAGE
+                return;      // timing-only ablation (wrong results)
+#endif
+                if (t >= 2) return;
+                Set& st = set[t & 1];
+                const int j = m;
+                const bool real = s + t + 2 < nslab;
+                if (j == 0) lw_begin(st);
+                // an element's whole division chain in one slot: the partner wave's MFMAs cover its latency (+1 % over link-by-link)
+                if (NORM && j >= 1 && j < 5) lw_norm(st, j - 1);
+                if (NORM && j == 5) lw_rotate();
+                if (j == 6 || j == 7) lw_split(st, j - 6, real);
+                if (j == 8) lw_store(nxt + t * XW_SLAB, 0);
+                if (j == 9) lw_store(nxt + t * XW_SLAB, 1);
+                if (j == 10) gload(s + t + 4, st);
               });
     }
-    __syncthreads();
-    const int t0 = o0;   // rotate: (o0, o1, o2) <- (o1, o2, o0)
-    o0 = o1; o1 = o2; o2 = t0;
-  };
-  for (int s = 0; s < nslab; s += 2) {
-    slab(s, std::integral_constant<int, 0>{});
-    slab(s + 1, std::integral_constant<int, 1>{});
+    const int t0 = cur; cur = nxt; nxt = t0;
   }
   if (pass == 0 && a.valid) {  // all-zero feature row == "no face" (FeatureExtractor.py:105-106); 8 lanes share a row
     const unsigned long long m = __ballot(nzbits != 0u);
     if ((tid & 7) == 0 && live) a.valid[row0 + srow] = ((m >> (c.lane & 56)) & 0xFFull) ? 1 : 0;
   }
 }
+
+// Timing-only diagnostic build (-DHX_STAMPS, tools/w8_stage_shares.py): per-wave s_memtime stamps at the trunk's stage boundaries into
+// the buffer passed as `latent` (16 slots per wave, 8 waves per tile), the tail's own stamps (encoder_heads_f16x2_dev.h) behind them.
+#ifdef HX_STAMPS
+#define W8S(i)                                                                                                          \
+  do {                                                                                                                  \
+    if (a.latent && c.lane == 0)                                                                                        \
+      reinterpret_cast<unsigned long long*>(a.latent)[((size_t)blockIdx.x * 8 + c.wv) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define W8S_WALL(i)                                                                                                     \
+  do {                                                                                                                  \
+    if (a.latent && c.lane == 0)                                                                                        \
+      reinterpret_cast<unsigned long long*>(a.latent)[((size_t)blockIdx.x * 8 + c.wv) * 16 + (i)] = wall_clock64();     \
+  } while (0)
+#else
+#define W8S(i) do { } while (0)
+#define W8S_WALL(i) do { } while (0)
+#endif
 
 template <bool VEC4, bool NORM>
 __global__ __launch_bounds__(512) void encoder_heads_f16x2_w8_kernel(Args a) {
@@ -215,6 +268,9 @@ __global__ __launch_bounds__(512) void encoder_heads_f16x2_w8_kernel(Args a) {
   c.wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0..7
   const int jw = c.wv >> 1, nbh = c.wv & 1;              // the job this wave shares with its partner, and its half of the job's blocks
   const int64_t row0 = (int64_t)blockIdx.x * TILE_FACES;
+#ifdef W8_PRIO   // experiment: static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+  if (c.wv >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
   {  // E0 (two passes of 512 neurons, split accumulators) interleaved with the two K halves of E1
     constexpr int WSTEP1 = 4 * 2 * 64;
@@ -236,12 +292,15 @@ __global__ __launch_bounds__(512) void encoder_heads_f16x2_w8_kernel(Args a) {
             park[512 * ((nb * 2 + fb) * 4 + q)] = f32x4{acc1[nb][fb][4 * q], acc1[nb][fb][4 * q + 1], acc1[nb][fb][4 * q + 2], acc1[nb][fb][4 * q + 3]};
     };
     park_acc1();
+    W8S(0);
+    W8S_WALL(14);
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       {
         f32x16 acc0[2][2], acc0s[2][2];
         stage_e0_pass_w8<VEC4, NORM>(c, a, row0, tid, pass, jw, nbh, acc0, acc0s);
         add_acc<2, 2>(acc0, acc0s);
+        W8S(1 + 4 * pass);
         // layer 1's accumulators back from LDS before the h1 half image is (over)written
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
@@ -256,6 +315,7 @@ __global__ __launch_bounds__(512) void encoder_heads_f16x2_w8_kernel(Args a) {
         job_store<2, 2, ACT_RELU>(c, acc0, O_H1H, P_H1H, S_H1H, 128 * jw + 64 * nbh, 0, inv0);
       }
       __syncthreads();
+      W8S(2 + 4 * pass);
       {  // layer 1 over this K half; its small products are added at the end of the half
         f32x16 acc1s[2][2];
         zero_acc<2, 2>(acc1s);
@@ -263,12 +323,15 @@ __global__ __launch_bounds__(512) void encoder_heads_f16x2_w8_kernel(Args a) {
                                 32 * S_H1H * 2);
         add_acc<2, 2>(acc1, acc1s);
       }
+      W8S(3 + 4 * pass);
       __syncthreads();   // H1H is free again (pass 0: for the parked set and pass 1's store; pass 1: for H2)
       if (pass == 0) park_acc1();
+      W8S(4 + 4 * pass);
     }
     job_store<2, 2, ACT_RELU>(c, acc1, O_H2, P_H2, S_H2, 128 * jw + 64 * nbh, 0, c.hdr.inv_scale[ST_E1]);
   }
   __syncthreads();
+  W8S(9);
   // E2: 512 -> 256, ReLU, split accumulators; job jw's block nbh.  h3 overwrites h2 => barrier between the K loop and the store
   Ctx ct = c;
   ct.wv = c.wv & 3;                                       // the tail's wave index (waves 4-7 only fetch with it, then end)
@@ -282,13 +345,22 @@ __global__ __launch_bounds__(512) void encoder_heads_f16x2_w8_kernel(Args a) {
     const h8* w2 = c.blob8 + c.hdr.w_off(ST_E2) + (size_t)jw * c.hdr.job_w16(ST_E2) + (nbh * 2) * 64 + c.lane;
     kloop<1, 2, 32, WSTEP2>(acc2, acc2s, w2, c.lds + O_H2 + (c.f * S_H2 + 8 * c.h) * 2, P_H2, 32 * S_H2 * 2);
     add_acc<1, 2>(acc2, acc2s);
+    W8S(10);
     tail_pre_e3<false>(ct, acc3, wr3);                    // E3's global fetches in front of the store and the barriers
     __syncthreads();
     job_store<1, 2, ACT_RELU>(c, acc2, O_H3, P_H3, S_H3, 64 * jw + 32 * nbh, 0, c.hdr.inv_scale[ST_E2]);
   }
   __syncthreads();
+  W8S(11);
+  W8S_WALL(15);
   if (c.wv >= 4) return;   // waves 4-7 end here; the tail's barriers wait only for the surviving waves (see the header)
+#ifdef HX_STAMPS
+  Args at = a;             // the tail's stamps (32 slots per wave, 4 waves per tile) behind the trunk's
+  if (a.latent) at.latent = a.latent + (size_t)gridDim.x * 8 * 16 * 2;
+  tail_stages<false>(ct, at, row0, acc3, wr3);
+#else
   tail_stages<false>(ct, a, row0, acc3, wr3);
+#endif
 }
 
 }  // namespace hx

@@ -843,6 +843,34 @@ def test_small_batch_path_is_bit_identical_to_the_fused_kernel(F, B, hx, head_sd
     assert np.degrees(np.abs(b.cpu().numpy() - ref).max()) <= POSE_TOL_DEG
 
 
+@pytest.mark.parametrize("F,B", [(1404, 300), (1404, 64), (136, 77), (13, 5), (1407, 130)])
+def test_strict_eight_wave_kernel_equals_the_four_wave_one(F, B, head_sds, device, monkeypatch):
+    """NLML_MODE_F16X2S runs on the eight-wave kernel (encoder_heads_f16x2_w8.hip: a trunk job shared by a pair of waves, waves 4-7
+    ending before the tail); the four-wave instantiation stays reachable through NLML_K2_STRICT_W4=1.  Per accumulator both issue the
+    same MFMAs in the same order: pose, latent and validity are the same bits -- from features (incl. widths that are not a multiple
+    of 4: the scalar staging path) and, at the reference width, from raw landmarks with the fused normalisation."""
+    sd = synth.encoder_state_dict(F, seed=3)
+    blob = _blob_hx(sd, head_sds, device, "f16x2s")
+    x = synth.features(B, F, seed=9)
+    x[3] = 0.0
+    xt = torch.from_numpy(x).to(device)
+    monkeypatch.delenv("NLML_K2_STRICT_W4", raising=False)
+    a = ops.encoder_heads_fwd(xt, blob, F, return_latent=True, return_valid=True)
+    raw = torch.from_numpy(synth.raw_landmarks(B, seed=4)).to(device) if F == 1404 else None
+    ar = ops.landmarks_to_pose(raw, blob, True, return_latent=True, return_valid=True) if raw is not None else None
+    monkeypatch.setenv("NLML_K2_STRICT_W4", "1")
+    b = ops.encoder_heads_fwd(xt, blob, F, return_latent=True, return_valid=True)
+    br = ops.landmarks_to_pose(raw, blob, True, return_latent=True, return_valid=True) if raw is not None else None
+    monkeypatch.delenv("NLML_K2_STRICT_W4")
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    if raw is not None:
+        for u, v in zip(ar, br):
+            assert torch.equal(u, v)
+    ref = EH.forward_numpy(x, EH.Params(sd, head_sds), np.float64)
+    assert np.degrees(np.abs(a[0].cpu().numpy() - ref).max()) <= POSE_TOL_DEG
+
+
 @pytest.mark.parametrize("hx", HX_MODES)
 def test_small_batch_path_landmarks_workspace_and_errors(hx, head_sds, device):
     """Raw-landmark entry of the small-batch path: same bits as the fused launch incl. the validity mask; garbage (NaN)

@@ -11,6 +11,7 @@ dev = torch.device("cuda:0")
 heads = weights.load_head_state_dicts(os.path.join(ROOT, "models"))
 sd = synth.encoder_state_dict(1404, seed=0)
 blob = torch.from_numpy(weights.pack_blob(sd, heads, _lib.MODE_F16X2S)).to(dev)
+bad = 0
 for B in (64, 1, 100, 4096 + 37):
     raw_np = synth.raw_landmarks(B, seed=5)
     raw = torch.from_numpy(raw_np).to(dev)
@@ -24,3 +25,6 @@ for B in (64, 1, 100, 4096 + 37):
     feats = ops.normalize_ipd(raw, True)
     o3 = ops.encoder_heads_fwd(feats, blob, 1404)
     print("   features path == fused:", torch.equal(o3, out), flush=True)
+    ok = torch.equal(out, o2) and torch.equal(lat, l2) and torch.equal(val, v2) and torch.equal(o3, out) and err < 1e-4
+    bad = bad + (0 if ok else 1)
+print("QUICK_W8", "PASS" if bad == 0 else f"FAIL ({bad} shapes)")
