@@ -178,47 +178,28 @@ def tucker_objective(Wm: torch.Tensor, x: torch.Tensor, params: torch.Tensor, co
 
 
 # ---------------------------------------------------------------------------------------------
-# torch.ops.nlml_hpe.* registration (SURVEY.md 8b "Underlying op").  The custom ops are thin
-# schemas over the functions above, so the HIP path is reachable from TorchScript-style call
-# sites (torch.ops.nlml_hpe.encoder_heads_fwd(x, blob, F)) as well as from Python.
-def _register_custom_ops():
-    lib = torch.library
+# torch.ops.nlml_hpe.* (SURVEY.md 8b "Underlying op") come from COMPILED code: csrc/torch_ops.cpp, a TORCH_LIBRARY shim over the same
+# C ABI (shape / dtype checks, torch's allocator, the operand device's current stream), built next to this file as
+# libnlml_torch_ops.so by csrc/Makefile.  Registered: normalize_ipd, encoder_heads_fwd, landmarks_to_pose, encoder_heads_fwd_small,
+# landmarks_to_pose_small (explicit workspace), landmarks_to_pose_valid (pose + face mask: the video tick's forward), tucker_objective, tucker_powell, video_post, cosine_table.  GPU backend only: a CPU
+# tensor has no kernel to dispatch to and raises.  A missing library raises here -- the ops are part of the boundary.
+import os as _os
 
-    @lib.custom_op("nlml_hpe::normalize_ipd", mutates_args=())
-    def _normalize_ipd(raw: torch.Tensor, normalize: bool) -> torch.Tensor:
-        return normalize_ipd(raw, normalize)
-
-    @_normalize_ipd.register_fake
-    def _(raw, normalize):
-        return raw.new_empty((raw.shape[0], F_REF))
-
-    @lib.custom_op("nlml_hpe::encoder_heads_fwd", mutates_args=())
-    def _encoder_heads_fwd(x: torch.Tensor, packed_w: torch.Tensor, F: int) -> torch.Tensor:
-        return encoder_heads_fwd(x, packed_w, F)
-
-    @_encoder_heads_fwd.register_fake
-    def _(x, packed_w, F):
-        return x.new_empty((x.shape[0], 3))
-
-    @lib.custom_op("nlml_hpe::landmarks_to_pose", mutates_args=())
-    def _landmarks_to_pose(raw: torch.Tensor, packed_w: torch.Tensor, normalize: bool) -> torch.Tensor:
-        return landmarks_to_pose(raw, packed_w, normalize)
-
-    @_landmarks_to_pose.register_fake
-    def _(raw, packed_w, normalize):
-        return raw.new_empty((raw.shape[0], 3))
-
-    @lib.custom_op("nlml_hpe::tucker_objective", mutates_args=())
-    def _tucker_objective(Wm: torch.Tensor, x: torch.Tensor, params: torch.Tensor, cos_params: torch.Tensor,
-                          order: str = "reference") -> torch.Tensor:
-        return tucker_objective(Wm, x, params, cos_params, order=order)
-
-    @_tucker_objective.register_fake
-    def _(Wm, x, params, cos_params, order="reference"):
-        return params.new_empty((params.shape[0],))
+TORCH_OPS_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libnlml_torch_ops.so")
 
 
-_register_custom_ops()   # a failure here raises: torch.ops.nlml_hpe.* is part of the boundary, not a convenience
+def _load_torch_ops():
+    if not _os.path.exists(TORCH_OPS_PATH):
+        raise _lib.NlmlError(f"{TORCH_OPS_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(make -C nlml_hpe_amd/csrc); torch.ops.nlml_hpe.* are registered from it")
+    _lib.lib()                                  # the C ABI library the shim links against, checked symbol by symbol first
+    torch.ops.load_library(TORCH_OPS_PATH)
+    for name in ("normalize_ipd", "encoder_heads_fwd", "landmarks_to_pose", "encoder_heads_fwd_small", "landmarks_to_pose_small",
+                 "landmarks_to_pose_valid", "tucker_objective", "tucker_powell", "video_post", "cosine_table"):
+        getattr(torch.ops.nlml_hpe, name)       # AttributeError if the library did not register it
+
+
+_load_torch_ops()
 
 
 def tucker_powell(Wm: torch.Tensor, x: torch.Tensor, cos_params: torch.Tensor, x0: torch.Tensor | None = None, order="reference"):

@@ -52,9 +52,17 @@ class VideoPoseTracker:
         """raw landmarks f32[S,468,3] of this tick (all-zero rows = no face) -> (smoothed, centre, endpoints, valid).
         valid[s] is True only where this tick was APPLIED to stream s: a face was found AND its pose is finite (a stream skipped for
         a NaN/Inf pose keeps its previous outputs and must not be saved as a new result; the reference raises on such a frame)."""
-        pose, valid = self.model.from_landmarks(raw, normalize=True, return_valid=True)
-        sm, c, ep = self.post(pose, raw, valid)
-        return sm, c, ep, self.updated.bool()
+        # both launches through the compiled torch.ops (csrc/torch_ops.cpp): at 64 faces the Python wrappers' checks, allocations and
+        # ctypes marshalling were ~2/3 of the tick's host time (tools/host_hop.py)
+        m = self.model
+        ops._need_cuda(raw, "raw", torch.float32)
+        if tuple(raw.shape) != (self.S, 468, 3):
+            raise ValueError(f"expected landmarks [{self.S},468,3]")
+        ws = ops._small_workspace(self.S, ops.F_REF, m.device) if m._small(self.S) else None
+        pose, valid = torch.ops.nlml_hpe.landmarks_to_pose_valid(raw, m.blob, True, ws)
+        torch.ops.nlml_hpe.video_post(pose, raw, valid, self.frame_w, self.frame_h, self.alpha, self.max_jump, self.size,
+                                      self.state, self.smoothed, self.centre, self.endpoints, self.updated)
+        return self.smoothed, self.centre, self.endpoints, self.updated.bool()
 
 
 class GraphedTick:

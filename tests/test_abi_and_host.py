@@ -166,6 +166,22 @@ def test_mode_names_and_default_are_the_parity_modes():
         M.HIPPoseModel(synth.encoder_state_dict(136, 0), weights.load_head_state_dicts("models"), device="cpu")
 
 
+def test_torch_ops_come_from_the_compiled_library():
+    """torch.ops.nlml_hpe.* are registered by libnlml_torch_ops.so (csrc/torch_ops.cpp), not by Python closures: the library exists
+    next to the C ABI one, importing the package loads it, every op resolves with its schema, a CPU tensor finds no kernel (there is
+    no CPU path behind the ops) and the Meta kernels give shapes without a GPU."""
+    import torch
+    from nlml_hpe_amd import ops
+    assert os.path.exists(ops.TORCH_OPS_PATH)
+    schema = str(torch.ops.nlml_hpe.landmarks_to_pose_small.default._schema)
+    assert "Tensor workspace" in schema and "bool normalize" in schema
+    assert "Tensor(a!) state" in str(torch.ops.nlml_hpe.video_post.default._schema) and "Tensor(e!) updated" in str(torch.ops.nlml_hpe.video_post.default._schema)
+    with pytest.raises(NotImplementedError):
+        torch.ops.nlml_hpe.landmarks_to_pose(torch.zeros(2, 468, 3), torch.zeros(16, dtype=torch.uint8), True)
+    m = torch.ops.nlml_hpe.landmarks_to_pose(torch.zeros(7, 468, 3, device="meta"), torch.zeros(16, dtype=torch.uint8, device="meta"), True)
+    assert tuple(m.shape) == (7, 3)
+
+
 def test_mode_and_order_names():
     assert _lib.mode_from_name("f16x2") == _lib.MODE_F16X2 and _lib.mode_from_name(0) == _lib.MODE_F32
     assert _lib.td_order_from_name("reference") == _lib.TD_ORDER_REFERENCE and _lib.td_order_from_name(0) == _lib.TD_ORDER_FAST

@@ -1196,18 +1196,24 @@ def test_tucker_objective_beyond_2_31_elements(order, tucker_art, device):
 
 # ---- round 3: paths that had never executed (ADVICE) -------------------------------------------------
 def test_registered_custom_ops_match_the_python_ops(head_sds, tucker_art, device):
-    """torch.ops.nlml_hpe.* (SURVEY.md 8b "Underlying op") -- the registered schemas reach the same C-ABI launches as nlml_hpe_amd.ops:
-    identical bits."""
+    """torch.ops.nlml_hpe.* (SURVEY.md 8b "Underlying op"), registered from COMPILED code (csrc/torch_ops.cpp, a TORCH_LIBRARY shim over
+    the C ABI) -- the schemas reach the same C-ABI launches as nlml_hpe_amd.ops: identical bits, for every registered op."""
     from nlml_hpe_amd import _lib
     raw = torch.from_numpy(synth.raw_landmarks(200, seed=3)).to(device)
     feats = ops.normalize_ipd(raw, True)
     assert torch.equal(torch.ops.nlml_hpe.normalize_ipd(raw, True), feats)
     assert torch.equal(torch.ops.nlml_hpe.normalize_ipd(raw, False), ops.normalize_ipd(raw, False))
     sd = synth.encoder_state_dict(1404, seed=0)
-    for mode in ("f16x2", "f32", "bf16"):
+    for mode in ("f16x2s", "f16x2", "f32", "bf16"):
         blob = torch.from_numpy(weights.pack_blob(sd, head_sds, _lib.mode_from_name(mode))).to(device)
         assert torch.equal(torch.ops.nlml_hpe.encoder_heads_fwd(feats, blob, 1404), ops.encoder_heads_fwd(feats, blob, 1404)), mode
         assert torch.equal(torch.ops.nlml_hpe.landmarks_to_pose(raw, blob, True), ops.landmarks_to_pose(raw, blob, True)), mode
+        if mode in HX_MODES:     # the layer-per-launch forms, workspace passed explicitly
+            ws = torch.empty(_lib.lib().nlml_encoder_heads_small_workspace_bytes(200, 1404), dtype=torch.uint8, device=device)
+            assert torch.equal(torch.ops.nlml_hpe.encoder_heads_fwd_small(feats, blob, 1404, ws), ops.encoder_heads_fwd(feats, blob, 1404)), mode
+            assert torch.equal(torch.ops.nlml_hpe.landmarks_to_pose_small(raw, blob, True, ws), ops.landmarks_to_pose(raw, blob, True)), mode
+            with pytest.raises(Exception):
+                torch.ops.nlml_hpe.landmarks_to_pose_small(raw, blob, True, ws[:1024])               # too small a workspace: the ABI's error, raised
     Wm = torch.from_numpy(tucker_art["W"].reshape(135, 1404)).to(device)
     cp = torch.from_numpy(_cos_params(tucker_art)).to(device)
     P = torch.from_numpy(synth.tucker_params(40, 5, seed=5)).to(device)
@@ -1217,6 +1223,32 @@ def test_registered_custom_ops_match_the_python_ops(head_sds, tucker_art, device
     assert torch.equal(torch.ops.nlml_hpe.tucker_objective(Wm, X, P, cp, "fast"), ops.tucker_objective(Wm, X, P, cp, order="fast"))
     with pytest.raises(Exception):
         torch.ops.nlml_hpe.encoder_heads_fwd(feats.cpu(), blob, 1404)                                 # no CPU path behind the op either
+    with pytest.raises(Exception):
+        torch.ops.nlml_hpe.tucker_objective(Wm, X, P, cp, "sideways")
+    # TD end to end: FX5-sized run, both the op and the Python wrapper walk the same device Powell
+    Xg = feats[:16].contiguous()
+    got = torch.ops.nlml_hpe.tucker_powell(Wm, Xg, cp)
+    want = ops.tucker_powell(Wm, Xg, cp)
+    for g_, k_ in zip(got, ("x", "fun", "nfev", "nit", "status")):
+        assert torch.equal(g_, want[k_]), k_
+    # one video tick: state updated in place, outputs and the "applied" mask as nlml_video_post_ex gives them to video.py
+    from nlml_hpe_amd.model import HIPPoseModel
+    from nlml_hpe_amd.video import ALPHA, AXIS_SIZE, MAX_CENTER_JUMP, VideoPoseTracker
+    mdl = HIPPoseModel(sd, head_sds, device=device)
+    tr = VideoPoseTracker(mdl, 64, 1920, 1080)
+    state = torch.zeros((64, 6), dtype=torch.float64, device=device)
+    sm2, c2, ep2 = (torch.zeros(sh, dtype=torch.float64, device=device) for sh in ((64, 3), (64, 2), (64, 3, 2)))
+    upd2 = torch.zeros((64,), dtype=torch.uint8, device=device)
+    r64 = raw[:64].contiguous()
+    r64[5] = 0.0                                                                                       # a stream without a face
+    for _ in range(3):
+        pose, valid = mdl.from_landmarks(r64, normalize=True, return_valid=True)
+        sm, c, ep = tr.post(pose, r64, valid)
+        torch.ops.nlml_hpe.video_post(pose, r64, valid.to(torch.uint8), 1920.0, 1080.0, ALPHA, MAX_CENTER_JUMP, AXIS_SIZE, state, sm2, c2, ep2, upd2)
+        assert torch.equal(sm, sm2) and torch.equal(c, c2) and torch.equal(ep, ep2) and torch.equal(tr.updated, upd2)
+        assert torch.equal(state, tr.state) and not bool(upd2[5]) and bool(upd2[4])
+    ang = torch.linspace(-1.0, 1.0, 101, device=device)
+    assert torch.equal(torch.ops.nlml_hpe.cosine_table(ang, cp[0]), ops.cosine_table(ang, cp[0]))
 
 
 def test_split_f16_every_face_of_a_tile_overflows(head_sds, device):

@@ -25,17 +25,10 @@ forms = {
     "ops.landmarks_to_pose_small (Python wrapper: checks, torch.empty, device guard, ctypes)": lambda: ops.landmarks_to_pose_small(raw, blob, True),
     "C ABI nlml_landmarks_to_pose via ctypes, preallocated buffers (1 launch)": lambda: L.nlml_landmarks_to_pose(*args_fused),
     "ops.landmarks_to_pose (Python wrapper, 1 launch)": lambda: ops.landmarks_to_pose(raw, blob, True),
-    "torch.ops.nlml_hpe.landmarks_to_pose (registered op -> the same wrapper, 1 launch)": lambda: torch.ops.nlml_hpe.landmarks_to_pose(raw, blob, True),
+    "torch.ops.nlml_hpe.landmarks_to_pose (compiled op, csrc/torch_ops.cpp, 1 launch)": lambda: torch.ops.nlml_hpe.landmarks_to_pose(raw, blob, True),
 }
-if hasattr(torch.ops.nlml_hpe, "landmarks_to_pose_small"):
-    forms["torch.ops.nlml_hpe.landmarks_to_pose_small (registered op, 5 launches)"] = lambda: torch.ops.nlml_hpe.landmarks_to_pose_small(raw, blob, True)
-try:
-    from nlml_hpe_amd import _C                                                             # compiled TORCH_LIBRARY shim, if built
-    if _C.available():
-        forms["torch.ops.nlml_hpe_c.landmarks_to_pose_small (compiled shim, 5 launches)"] = lambda: torch.ops.nlml_hpe_c.landmarks_to_pose_small(raw, blob, True)
-        forms["torch.ops.nlml_hpe_c.landmarks_to_pose (compiled shim, 1 launch)"] = lambda: torch.ops.nlml_hpe_c.landmarks_to_pose(raw, blob, True)
-except ImportError:
-    pass
+forms["torch.ops.nlml_hpe.landmarks_to_pose_small (compiled op, explicit workspace, 5 launches)"] = lambda: torch.ops.nlml_hpe.landmarks_to_pose_small(raw, blob, True, ws)
+forms["torch.ops.nlml_hpe.landmarks_to_pose_valid (compiled op: pose + face mask, 5 launches)"] = lambda: torch.ops.nlml_hpe.landmarks_to_pose_valid(raw, blob, True, ws)
 N, REP = 100, 20
 print(f"faces {B}, {REP} x {N} calls per form")
 for name, fn in forms.items():
@@ -61,7 +54,7 @@ if B == 64:
     mdl = HIPPoseModel(sd, heads, device=dev)
     tr = VideoPoseTracker(mdl, 64, 1920, 1080)
     gt = GraphedTick(VideoPoseTracker(mdl, 64, 1920, 1080))
-    for label, fn in (("tick eager (forward_small + video_post through Python)", lambda: tr.tick(raw)), ("tick hipGraph replay", lambda: gt.replay())):
+    for label, fn in (("tick eager (VideoPoseTracker.tick: two compiled ops)", lambda: tr.tick(raw)), ("tick hipGraph replay", lambda: gt.replay())):
         for _ in range(50):
             fn()
         host, full = [], []
