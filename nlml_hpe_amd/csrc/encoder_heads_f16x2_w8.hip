@@ -151,10 +151,7 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
   // steps) before it is written to LDS.  (Four sets -- loads two iterations ahead, for pass 0's x from HBM -- are eight more registers,
   // and at 256 per wave those spill into the K loops.)  vmcnt counts in issue order: encoder_heads_f16x2.hip.
   Set set[2];
-#ifndef W8_RING
-#define W8_RING 4
-#endif
-  constexpr int R0 = W8_RING, D0 = R0 - 1;   // weight ring (4: K step ks in slot ks % 4 = its step within the iteration)
+  constexpr int R0 = 4, D0 = R0 - 1;   // weight ring: K step ks in slot ks % 4 = its step within the iteration
   h8 wr[R0][NB][2];
   gload(0, set[0]);
   gload(1, set[1]);
@@ -200,9 +197,6 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
       // iteration may overwrite the old one from its first slot on.
 #ifndef W8_ABL_NOBAR
       if (t == 3) __syncthreads();
-#endif
-#ifdef W8_ALTPRIO   // experiment: the two waves of a SIMD take turns at the higher priority, step by step
-      if (((c.wv >> 2) ^ t) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
       step_fine<NB, NFB>(acc, accS, wr[t], xr[t & 1], wr[(t + D0) % R0], wfrag(ks + D0), true,
               [&](int fb, int pp) {                         // the next K step's x operands
@@ -268,9 +262,6 @@ __global__ __launch_bounds__(512) void encoder_heads_f16x2_w8_kernel(Args a) {
   c.wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0..7
   const int jw = c.wv >> 1, nbh = c.wv & 1;              // the job this wave shares with its partner, and its half of the job's blocks
   const int64_t row0 = (int64_t)blockIdx.x * TILE_FACES;
-#ifdef W8_PRIO   // experiment: static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-  if (c.wv >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
 
   {  // E0 (two passes of 512 neurons, split accumulators) interleaved with the two K halves of E1
     constexpr int WSTEP1 = 4 * 2 * 64;
