@@ -60,6 +60,8 @@ struct EncArgs {
   uint8_t* valid;       // [B] or null
   float* pre_tanh;      // [B,64] or null: E4 accumulators before the Tanh (test hook, DBG build only)
   unsigned long long* stamps;  // [tiles,4 waves,16] s_memtime at stage boundaries (DBG build only)
+  int reeval_over;      // >= 0: RE-EVALUATION launch behind a split-f16 launch (NLML_MODE_F16X2S): a tile is computed only if more
+                        // than this many of its faces hold a non-finite pose in `out`, and only those faces are written; -1: off
 };
 
 template <int ACT>
@@ -630,6 +632,24 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
   const int wv = c.wv;
   constexpr int TILE = 32 * NFB;
   const int64_t row0 = (int64_t)blockIdx.x * TILE;
+  // Re-evaluation launch: the split-f16 kernel before this one left a NON-FINITE pose for every face whose activations do not fit f16
+  // (un-normalised pixel-scale landmarks, the reference's ipd == 0 branch) and re-evaluated such faces itself where a tile had few;
+  // a tile with MORE than reeval_over of them comes here -- the whole tile through the f32 matrix cores (this kernel, its own blob
+  // image), only the non-finite faces written.  Every other tile ends at once (one 768-byte read).
+  // The count is over the split-f16 kernels' 64-face tile whatever this launch's own tiling (a 32-face tile looks at its parent).
+  unsigned long long redo = ~0ull;
+  if (a.reeval_over >= 0) {
+    const int64_t r = (row0 & ~(int64_t)63) + c.lane;
+    bool bad = false;
+    if (r < a.B) {
+      const float p0 = a.out[r * 3 + 0], p1 = a.out[r * 3 + 1], p2 = a.out[r * 3 + 2];
+      bad = !(__builtin_isfinite(p0) && __builtin_isfinite(p1) && __builtin_isfinite(p2));
+    }
+    const unsigned long long parent = __ballot(bad);
+    if (__popcll(parent) <= a.reeval_over) return;   // uniform over the workgroup: every wave reads the same 64 poses
+    redo = NFB == 2 ? parent : (parent >> (row0 & 32)) & 0xffffffffull;
+    if (redo == 0) return;                           // (a 32-face tile whose half of the parent is clean)
+  }
 
   {  // ---- layers 0 and 1 interleaved in two passes over x (see header), both summed in blocks of 128 k (fold_block)
     E0Stager g;
@@ -699,7 +719,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
           }
       NLML_STAMP(4 + 4 * pass);
     }
-    if (a.valid) {  // all-zero feature row == "no face" (FeatureExtractor.py:105-106)
+    if (a.valid && a.reeval_over < 0) {  // all-zero feature row == "no face" (FeatureExtractor.py:105-106)
       const unsigned long long m0 = __ballot(g.nzbits0 != 0u), m1 = __ballot(g.nzbits1 != 0u);
       if ((tid & 7) == 0) {
         const int sh = c.lane & 56;
@@ -751,7 +771,8 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
   if (a.latent) {  // optional: the encoder output before the split (Model_Builder.py:58)
     for (int i = tid; i < TILE * NLML_LATENT; i += 256) {
       const int ff = i / NLML_LATENT, n = i % NLML_LATENT;
-      if (row0 + ff < a.B) a.latent[(row0 + ff) * NLML_LATENT + n] = lds[O_LAT + ff * S_LAT + 8 * (n / 3) + (n % 3)];
+      if (row0 + ff < a.B && ((redo >> ff) & 1))
+        a.latent[(row0 + ff) * NLML_LATENT + n] = lds[O_LAT + ff * S_LAT + 8 * (n / 3) + (n % 3)];
     }
   }
   // ---- heads (yaw, pitch, roll = g 0,1,2), one 32-face block at a time.  A stage's jobs are (head,
@@ -837,7 +858,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
     if (wv < 3) {  // H4: 64 -> 1; neuron on accumulator row 0 = register 0 of lanes 0..31
       f32x16 acc[1][1];
       job_compute<1, 1, ST_H4>(c, wv, acc, lds + O_HD, S_HD, 64 * wv, 0);
-      if (c.h == 0 && row0 + face0 + c.f < a.B) a.out[(row0 + face0 + c.f) * 3 + wv] = acc[0][0][0];
+      if (c.h == 0 && row0 + face0 + c.f < a.B && ((redo >> (face0 + c.f)) & 1)) a.out[(row0 + face0 + c.f) * 3 + wv] = acc[0][0][0];
     }
     __syncthreads();  // hd / ha regions are reused by the next face block
   }
@@ -846,9 +867,10 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f32_kernel(EncArgs a) {
 
 int launch_encoder_heads_f32(const float* x, int64_t ldx, const float* raw, int normalize,
                              int64_t B, int F, const void* blob, float* out, float* latent,
-                             uint8_t* valid, float* pre_tanh, unsigned long long* stamps, void* stream) {
+                             uint8_t* valid, float* pre_tanh, unsigned long long* stamps, void* stream, int reeval_over) {
   if (B == 0) return 0;
   EncArgs a;
+  a.reeval_over = reeval_over;
   a.B = B;
   a.F = F;
   a.blob = blob;

@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
                             fetch_hook<8, 1, 2, ST_E3>(c, wv, acc3, wr3));
   __syncthreads();
   HXS(10);
-  tail_stages<false>(c, a, row0, acc3, wr3);
+  tail_stages<false, SPLIT ? STRICT_INKERNEL_RESCUE_MAX : 64>(c, a, row0, acc3, wr3);
   HXS_WALL(31);
 }
 
@@ -641,7 +641,11 @@ int launch_encoder_heads_f16x2(const float* x, int64_t ldx, const float* raw, in
   }
 #undef NLML_HX_LAUNCH
   const hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+  if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+  if (split)   // (the four-wave strict instantiation, NLML_K2_STRICT_W4=1: the same f32 re-evaluation launch as behind the eight-wave kernel)
+    return launch_encoder_heads_f32(x, ldx, raw, normalize, B, F, static_cast<const char*>(blob) + strict_f32_image_offset(F), out, latent,
+                                    nullptr, nullptr, nullptr, stream, STRICT_INKERNEL_RESCUE_MAX);
+  return 0;
 }
 
 }  // namespace nlml

@@ -609,7 +609,10 @@ __device__ __forceinline__ void tail_pre_e3(const Ctx& c, f32x16 (&acc)[1][TailE
   job_pre<1, TailE3<ONEFB>::NFB, ST_E3>(c, c.wv, acc, wr);
 }
 
-template <bool ONEFB = false>
+// RESCUE_UP_TO: the workgroup re-evaluates its non-finite faces itself (encoder_heads_f16x2_rescue.h: vector ALUs, four faces at a
+// time) when there are at most this many; with more it leaves them non-finite for the f32 re-evaluation launch that follows the
+// strict-fast kernels (encoder_heads.hip, reeval_over).  64 = always here (NLML_MODE_F16X2, which has no f32 image in its blob).
+template <bool ONEFB = false, int RESCUE_UP_TO = 64>
 __device__ __forceinline__ void tail_stages(const Ctx& c, const Args& a, int64_t row0, f32x16 (&acc3)[1][TailE3<ONEFB>::NFB],
                                             h8 (&wr3)[ring_slots(1, TailE3<ONEFB>::NFB)][1][2], int fbsel = 0) {
   const int wv = c.wv;
@@ -759,7 +762,7 @@ __device__ __forceinline__ void tail_stages(const Ctx& c, const Args& a, int64_t
     const bool mine = ONEFB ? c.h == 0 : true;
     const unsigned long long m = __ballot(mine && row0 + fl < a.B && *rescue_flag(c.lds, fl) != 0);
     const unsigned long long mask = ONEFB ? (m & 0xffffffffull) << (32 * fbsel) : m;
-    if (mask) rescue_tile(a.x, a.ldx, a.F, a.norm, a.blob, a.out, a.latent, c.lds, row0, mask);
+    if (mask && __popcll(mask) <= RESCUE_UP_TO) rescue_tile(a.x, a.ldx, a.F, a.norm, a.blob, a.out, a.latent, c.lds, row0, mask);
   }
 #endif
 }

@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
 // ---- the network's tail (E3, E4, E5 and the three heads: 8 of the 11 layers, 7 % of the FLOP) as ONE launch: a
 // workgroup per 32-FACE BLOCK copies its half of E2's output fragments into the H3 LDS image and runs the fused
 // kernel's tail_stages() on that block (two workgroups per tile: half the sequential stages of the 64-face form).
+template <int RESCUE_UP_TO>
 __global__ __launch_bounds__(256, 1) void tail_kernel(hx::Args a, const h8* __restrict__ xin, int buf_steps) {
   __shared__ __attribute__((aligned(16))) char lds[hx::LDS_BYTES];
   const int tid = threadIdx.x;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(hx::Args a, const h8* __re
         src[(size_t)step * STEP_UNITS + (fbsel * 2 + piece) * 64 + l];
   }
   __syncthreads();
-  hx::tail_stages<true>(c, a, row0, acc3, wr3, fbsel);
+  hx::tail_stages<true, RESCUE_UP_TO>(c, a, row0, acc3, wr3, fbsel);
 }
 
 static int e0_k16(int F) { return (F + 2 * hx::XS_COLS - 1) / (2 * hx::XS_COLS) * (2 * hx::XS_STEPS); }   // as pack.cpp
@@ -390,10 +391,15 @@ int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* r
     hx::Args ta{};
     ta.B = B; ta.F = F; ta.blob = blob; ta.out = out; ta.latent = latent; ta.valid = nullptr;
     ta.x = src; ta.ldx = sld; ta.norm = raw ? (normalize ? 1 : 0) : 0;   // the tail's slow path re-reads the face's input
-    hipLaunchKernelGGL(tail_kernel, dim3((unsigned)(2 * ntiles)), dim3(256), 0, st, ta, (const h8*)in, buf_steps);
+    if (split) hipLaunchKernelGGL(tail_kernel<STRICT_INKERNEL_RESCUE_MAX>, dim3((unsigned)(2 * ntiles)), dim3(256), 0, st, ta, (const h8*)in, buf_steps);
+    else hipLaunchKernelGGL(tail_kernel<64>, dim3((unsigned)(2 * ntiles)), dim3(256), 0, st, ta, (const h8*)in, buf_steps);
   }
   const hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+  if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+  if (split)   // the strict-fast mode's f32 re-evaluation launch, as behind its fused kernel (encoder_heads_f16x2_w8.hip)
+    return launch_encoder_heads_f32(x, ldx, raw, normalize, B, F, static_cast<const char*>(blob) + strict_f32_image_offset(F), out, latent,
+                                    nullptr, nullptr, nullptr, stream, STRICT_INKERNEL_RESCUE_MAX);
+  return 0;
 }
 
 }  // namespace nlml

@@ -348,9 +348,9 @@ __global__ __launch_bounds__(512) void encoder_heads_f16x2_w8_kernel(Args a) {
 #ifdef HX_STAMPS
   Args at = a;             // the tail's stamps (32 slots per wave, 4 waves per tile) behind the trunk's
   if (a.latent) at.latent = a.latent + (size_t)gridDim.x * 8 * 16 * 2;
-  tail_stages<false>(ct, at, row0, acc3, wr3);
+  tail_stages<false, STRICT_INKERNEL_RESCUE_MAX>(ct, at, row0, acc3, wr3);
 #else
-  tail_stages<false>(ct, a, row0, acc3, wr3);
+  tail_stages<false, STRICT_INKERNEL_RESCUE_MAX>(ct, a, row0, acc3, wr3);
 #endif
 }
 
@@ -377,7 +377,11 @@ int launch_encoder_heads_f16x2_w8(const float* x, int64_t ldx, const float* raw,
     else hipLaunchKernelGGL((hx::encoder_heads_f16x2_w8_kernel<false, false>), grid, block, 0, st, a);
   }
   const hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+  if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+  // tiles with more than STRICT_INKERNEL_RESCUE_MAX faces beyond f16's range: the whole tile again on the f32 matrix cores, from the
+  // f32 image behind the split-f16 one; every other tile of that launch ends after one 768-byte read (encoder_heads.hip)
+  return launch_encoder_heads_f32(x, ldx, raw, normalize, B, F, static_cast<const char*>(blob) + strict_f32_image_offset(F), out, latent,
+                                  nullptr, nullptr, nullptr, stream, STRICT_INKERNEL_RESCUE_MAX);
 }
 
 }  // namespace nlml

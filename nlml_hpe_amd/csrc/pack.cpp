@@ -107,10 +107,15 @@ size_t blob_bytes_for(int F, int mode) {
     units += (size_t)d.jobs * k8 * d.nb * 64 * pieces_of(mode);      // weights: 16 bytes per lane (and piece)
     units += (size_t)d.jobs * d.nb * 2 * 4;        // bias: 2 halves x 16 floats
   }
-  if (mode == NLML_MODE_F16X2S) units += 16;   // the same image as NLML_MODE_F16X2 plus 256 bytes: the mode is read off the size
   units += 4096;  // 64 KiB tail pad: the K loops prefetch up to 7 steps (<= 8 KiB) past a job's end
+  // NLML_MODE_F16X2S: the NLML_MODE_F16X2 image, 256 bytes, then a complete NLML_MODE_F32 image -- what the re-evaluation launch of
+  // the strict-fast mode reads (faces whose activations leave f16's range, when a tile has many: encoder_heads.hip).  The mode of a
+  // blob is still read off its size.
+  if (mode == NLML_MODE_F16X2S) units += 16 + blob_bytes_for(F, NLML_MODE_F32) / 16;
   return units * 16;
 }
+
+size_t strict_f32_image_offset(int F) { return blob_bytes_for(F, NLML_MODE_F16X2) + 256; }
 
 int pack_blob(int F, int mode, const float* const enc_w[6], const float* const enc_b[6],
               const float* const head_w[3][5], const float* const head_b[3][5],
@@ -224,6 +229,10 @@ int pack_blob(int F, int mode, const float* const enc_w[6], const float* const e
     cur = b_off + (size_t)d.jobs * d.nb * 8;
   }
   hdr->total16 = (uint32_t)(need / 16);
+  if (mode == NLML_MODE_F16X2S) {   // the f32 image behind the split-f16 one
+    const size_t off = strict_f32_image_offset(F);
+    if (int rc = pack_blob(F, NLML_MODE_F32, enc_w, enc_b, head_w, head_b, reinterpret_cast<char*>(blob) + off, blob_bytes - off)) return rc;
+  }
   if (f16x2) {   // the split-f16 kernels compute these offsets from k16_e0 instead of reading them (encoder_heads_f16x2_dev.h)
     for (int s = 0; s < NUM_STAGES; ++s) {
       const uint32_t k = hdr->k8_e0;

@@ -62,13 +62,16 @@ def test_packed_blob_walk_split_f16_mode(F, head_sds):
     err_deg = np.abs(np.degrees(out - ref)).max()
     assert err_deg <= 2e-5, err_deg                       # parity bar is 1e-4 deg; the split leaves ~1e-5
     assert np.abs(lat - EH.encoder_latent_numpy(x, P, np.float64)).max() <= 2e-6
-    # NLML_MODE_F16X2S: the same image (the header's mode and total-size words apart) plus 256 bytes of zero padding
+    # NLML_MODE_F16X2S: the same image (the header's mode and total-size words apart), 256 bytes of zero padding, then a complete
+    # NLML_MODE_F32 image: what the strict-fast mode's f32 re-evaluation launch reads (tiles with many faces beyond f16's range)
     blob_s = weights.pack_blob(sd, head_sds, _lib.MODE_F16X2S)
-    assert blob_s.nbytes == blob.nbytes + 256
+    blob_f32 = weights.pack_blob(sd, head_sds, _lib.MODE_F32)
+    assert blob_s.nbytes == blob.nbytes + 256 + blob_f32.nbytes
     a, b = blob.view(np.uint8), blob_s.view(np.uint8)
     diff = np.flatnonzero(a != b[:a.size])
-    assert set(diff // 4) == {3, 5} and a[12] == _lib.MODE_F16X2 and b[12] == _lib.MODE_F16X2S and not b[a.size:].any()
-    assert blob_s.view(np.uint32)[5] == blob.view(np.uint32)[5] + 16
+    assert set(diff // 4) == {3, 5} and a[12] == _lib.MODE_F16X2 and b[12] == _lib.MODE_F16X2S and not b[a.size:a.size + 256].any()
+    assert np.array_equal(b[a.size + 256:], blob_f32.view(np.uint8))
+    assert blob_s.view(np.uint32)[5] == blob.view(np.uint32)[5] + 16 + blob_f32.nbytes // 16
 
 
 def test_pack_rejects_bad_input(head_sds):
@@ -156,7 +159,7 @@ def test_mode_names_and_default_are_the_parity_modes():
     for F in (10, 13, 64, 136, 1404, 1407):
         sizes = [L.nlml_encoder_heads_packed_bytes(F, m) for m in (0, 1, 2, 3)]
         assert len(set(sizes)) == 4 and all(sizes), (F, sizes)
-        assert sizes[3] == sizes[2] + 256
+        assert sizes[3] == sizes[2] + 256 + sizes[0]      # strict-fast: the split-f16 image + 256 bytes + an f32 image
     default = inspect.signature(M.HIPPoseModel.__init__).parameters["mode"].default
     assert default == _lib.DEFAULT_MODE and default in (_lib.MODE_F16X2S, _lib.MODE_F32), \
         "the default must be a STRICT parity mode (inside the reference's own error): never f16x2 (1.10x), never bf16"
