@@ -73,11 +73,11 @@ int nlml_normalize_ipd(const float* raw, int64_t B, int normalize,
  *       1.25e-5 / 4.0e-5 / 8.7e-5 deg in p50 / p99 / max, no worse than the reference's own 1.7e-5 / 5.5e-5 / 9.9e-5);
  *       NLML_MODE_BF16 = bf16 weights and activations + bf16 MFMA, f32 accumulate (throughput mode:
  *       ~5x the faces/s; its error is ~0.1 deg max / 0.02 deg mean and is never claimed as parity);
- *       NLML_MODE_F16X2 = split-f16 parity mode: every f32 weight and activation is carried as two f16
+ *       NLML_MODE_F16X2 = split-f16 mode, OPT-IN, 1.10x THE REFERENCE'S ERROR: every f32 weight and activation is carried as two f16
  *       pieces (hi + lo, 22 significand bits) and a product runs as three f16 MFMAs with f32 accumulation.
  *       ~1e-5 deg from the reference on small poses; at the reference's operating range (FX3c) 1.86e-5 / 5.9e-5 / 1.22e-4 deg
  *       from the exact result in p50 / p99 / max = 1.10 / 1.08 / 1.24x the reference's own distance, 0.024 % of the faces beyond 1e-4
- *       deg; ~3x NLML_MODE_F32's faces/s (the bench default).  No input-range limit: a
+ *       deg; ~3x NLML_MODE_F32's faces/s (the default of this build's host layer until round 3; NLML_MODE_F16X2S since).  No input-range limit: a
  *       face whose activations leave f16's range (|v| >= 65520 -- e.g. the reference's ipd == 0 -> 1e-6 branch,
  *       FeatureExtractor.py:47-48) is re-evaluated inside the same launch in f32 on the vector ALUs from the same
  *       blob (csrc/encoder_heads_f16x2_rescue.h); NaN/Inf inputs give a non-finite pose, as in the reference.
@@ -91,10 +91,14 @@ int nlml_normalize_ipd(const float* raw, int64_t B, int normalize,
  *       (w_lo*x_hi, w_hi*x_lo) accumulate in registers of their own in layers 0 to 2 and join the big sum once per K
  *       block: the matrix instruction truncates its products to the running sum's exponent, which is what costs
  *       NLML_MODE_F16X2 its distance (profiles/r03_mfma_f16_numerics_probe.txt; that mode has room for the second accumulator set only from
- *       layer 1's second K half on).  Strict parity at matrix-core speed: on FX3c
- *       no farther from the exact result than the reference itself, at ~0.78x NLML_MODE_F16X2's faces/s (layer 0 runs in
- *       two passes over x to make room for the second accumulator set).  Same packed image as NLML_MODE_F16X2 (+256
- *       bytes, so the size still names the mode), same range behaviour and slow path.
+ *       layer 1's second K half on).  Strict parity at matrix-core speed, THE DEFAULT of the host layer: on FX3c
+ *       no farther from the exact result than the reference itself, at ~0.9x NLML_MODE_F16X2's faces/s (an eight-wave kernel,
+ *       csrc/encoder_heads_f16x2_w8.hip; layer 0 runs in two passes over x to make room for the second accumulator set).
+ *       Packed image: NLML_MODE_F16X2's, 256 bytes, then a complete NLML_MODE_F32 image (the size still names the mode).
+ *       Range behaviour: a tile with at most four faces beyond f16's range re-evaluates them itself as NLML_MODE_F16X2 does; a tile
+ *       with MORE is re-evaluated whole on the f32 matrix cores from the f32 image by a second launch that the forward entry points
+ *       enqueue behind the kernel (csrc/encoder_heads.hip, re-evaluation mode; it ends at once for every other tile): the strict
+ *       parity kernel's bits on those faces, and a batch in which EVERY face overflows runs 3x slower, not 40x.
  * The forward entry points recognise the mode of a blob by its size.
  */
 #define NLML_MODE_F32   0
