@@ -31,6 +31,35 @@ __device__ __forceinline__ double div_ipd_w8(double n, double d, double y) {   /
   return fma(r, y, q);
 }
 
+// One K step of a layer-0 pass (two neuron blocks x two face blocks, split accumulators): step_fine's products in step_fine's order
+// -- (w_lo, x_hi) and (w_hi, x_lo) into accS, (w_hi, x_hi) into acc, one MFMA per slot -- with the x operands in registers of their
+// own: the hi pieces double-buffered (read by the first and the last four MFMAs), the LO pieces SINGLE-buffered: their last reader is
+// MFMA 7 of 12, so the next step's lo pieces are fetched into the same registers behind MFMAs 8 and 9 -- eight registers fewer than
+// two full operand sets (at 256 registers per wave that is the difference between 93 and 87 spilled registers outside the K loops, and
+// +0.6 % faces/s on one box).
+template <typename XHi, typename XLo, typename Extra>
+__device__ __forceinline__ void step_w8(f32x16 (&acc)[2][2], f32x16 (&accS)[2][2], const h8 (&wcur)[2][2], const h8 (&xh)[2], h8 (&xl)[2],
+                                        h8 (&wnext)[2][2], const h8* __restrict__ wp, XHi xload_hi, XLo xload_lo, Extra extra) {
+#pragma unroll
+  for (int m = 0; m < 12; ++m) {
+    const int t = m / 4, nb = (m % 4) / 2, fb = m % 2;
+    if (t == 0) accS[nb][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[nb][1], xh[fb], accS[nb][fb], 0, 0, 0);
+    else if (t == 1) accS[nb][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[nb][0], xl[fb], accS[nb][fb], 0, 0, 0);
+    else acc[nb][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[nb][0], xh[fb], acc[nb][fb], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (m == 0) xload_hi(0);
+    if (m == 1) xload_hi(1);
+    if (m == 2) wnext[0][0] = wp[0];
+    if (m == 4) wnext[0][1] = wp[64];
+    if (m == 6) wnext[1][0] = wp[128];
+    if (m == 8) xload_lo(0);          // (xl's last reader was MFMA 7)
+    if (m == 9) xload_lo(1);
+    if (m == 10) wnext[1][1] = wp[192];
+    extra(m);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // One pass of layer 0 for 512 threads: x[64,F] f32 -> (optional IPD normalisation in f64, FeatureExtractor.py:30-66) -> hi/lo f16 ->
 // three rotating LDS slabs of 32 columns (thread = row tid/8, columns 4*(tid%8) .. +3); this wave computes neuron blocks 2*nbh, 2*nbh+1
 // of job 4*pass + jw for both face blocks with split accumulators (step_fine: `acc` takes w_hi*x_hi, `accS` the two small products).
@@ -148,8 +177,10 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
 #endif
 
   // TWO staging register sets (4 floats per thread each), slab q in set[q & 1]: a slab's global loads are issued one iteration (four K
-  // steps) before it is written to LDS.  (Four sets -- loads two iterations ahead, for pass 0's x from HBM -- are eight more registers,
-  // and at 256 per wave those spill into the K loops.)  vmcnt counts in issue order: encoder_heads_f16x2.hip.
+  // steps) before it is written to LDS.  In pass 0 x comes from HBM, and a load that has not returned holds back every weight load
+  // behind it in the in-order return queue: pass 0 takes ~10 k cycles longer than pass 1 (x from L2).  FOUR sets (loads two iterations
+  // ahead) fit the register budget since step_w8 single-buffers the lo operands, but need the loop unrolled by two for static set
+  // indices, and hipcc's allocation of that 96-MFMA body spills 166 registers, 30 reloads inside the loop: 1.25 ms against 0.84 (measured).
   Set set[2];
   constexpr int R0 = 4, D0 = R0 - 1;   // weight ring: K step ks in slot ks % 4 = its step within the iteration
   h8 wr[R0][NB][2];
@@ -173,15 +204,16 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
   typedef __attribute__((address_space(3))) const char LdsC;   // (address space 3 kept through the opaque copies below: ds_read, not flat_load)
   LdsC* const xb0 = (LdsC*)(c.lds + O_XW + rd0);
   LdsC* const xb1 = (LdsC*)(c.lds + O_XW + (rd0 ^ 32));
-  h8 xr[2][NFB][2];
+  h8 xh[2][NFB], xl[NFB];
   auto xread = [&](LdsC* base, int t, int fb, int pp) {     // x operand (fb, piece pp) of step t (0..3) of a buffer
     return *reinterpret_cast<const __attribute__((address_space(3))) h8*>(base + (t >> 1) * XW_SLAB + pp * XW_PLANE + fb * (32 * 64));
   };
   const int niter = nslab / 2;
 #pragma unroll
-  for (int fb = 0; fb < NFB; ++fb)
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) xr[0][fb][pp] = xread(xb0, 0, fb, pp);
+  for (int fb = 0; fb < NFB; ++fb) {
+    xh[0][fb] = xread(xb0, 0, fb, 0);
+    xl[fb] = xread(xb0, 0, fb, 1);
+  }
   int cur = 0, nxt = XW_BUF;   // byte offsets of the buffer being read / written
   for (int it = 0; it < niter; ++it) {
     const int s = 2 * it;
@@ -198,10 +230,9 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
 #ifndef W8_ABL_NOBAR
       if (t == 3) __syncthreads();
 #endif
-      step_fine<NB, NFB>(acc, accS, wr[t], xr[t & 1], wr[(t + D0) % R0], wfrag(ks + D0), true,
-              [&](int fb, int pp) {                         // the next K step's x operands
-                xr[(t + 1) & 1][fb][pp] = t < 3 ? xread(xc[(t + 1) & 1], t + 1, fb, pp) : xread(xn, 0, fb, pp);
-              },
+      step_w8(acc, accS, wr[t], xh[t & 1], xl, wr[(t + D0) % R0], wfrag(ks + D0),
+              [&](int fb) { xh[(t + 1) & 1][fb] = t < 3 ? xread(xc[(t + 1) & 1], t + 1, fb, 0) : xread(xn, 0, fb, 0); },
+              [&](int fb) { xl[fb] = t < 3 ? xread(xc[(t + 1) & 1], t + 1, fb, 1) : xread(xn, 0, fb, 1); },
               [&](int m) {   // the staging of slab s+2 (step 0) and s+3 (step 1), one piece behind an MFMA
 #ifdef W8_ABL_NOSTAGE
                 return;      // timing-only ablation (wrong results)
@@ -217,7 +248,7 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
                 if (j == 6 || j == 7) lw_split(st, j - 6, real);
                 if (j == 8) lw_store(nxt + t * XW_SLAB, 0);
                 if (j == 9) lw_store(nxt + t * XW_SLAB, 1);
-                if (j == 10) gload(s + t + 4, st);
+                if (j == 11) gload(s + t + 4, st);
               });
     }
     const int t0 = cur; cur = nxt; nxt = t0;
