@@ -94,6 +94,9 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
   struct Set { float v[4]; };
   auto gload = [&](int s, Set& st) {   // columns scol .. scol+3 of slab s
     s = s < nslab ? s : nslab - 1;
+#ifdef W8_ABL_XHOT   // timing-only ablation (wrong results): every slab's x comes from the row's first 128 bytes (L1 / L2 hot)
+    s = 0;
+#endif
     const int k = s * XS_COLS + scol;
     if (VEC4) {
       const int kc = k < F ? k : (NORM ? k - 12 * ((k - F + 15) / 12) : F - 4);   // phase-preserving clamp (zero weights there)
@@ -376,6 +379,8 @@ __global__ __launch_bounds__(512) void encoder_heads_f16x2_w8_kernel(Args a) {
   W8S(11);
   W8S_WALL(15);
   if (c.wv >= 4) return;   // waves 4-7 end here; the tail's barriers wait only for the surviving waves (see the header)
+  // (Measured and dropped: on their way out these waves TOUCHED the input rows of the tile that starts one tile time later -- one dword
+  // per line, so that its pass 0 finds x in the Infinity Cache instead of HBM: 0.852 ms against 0.834 without, same box.)
 #ifdef HX_STAMPS
   Args at = a;             // the tail's stamps (32 slots per wave, 4 waves per tile) behind the trunk's
   if (a.latent) at.latent = a.latent + (size_t)gridDim.x * 8 * 16 * 2;
