@@ -95,10 +95,10 @@ int nlml_normalize_ipd(const float* raw, int64_t B, int normalize,
  *       no farther from the exact result than the reference itself, at ~0.9x NLML_MODE_F16X2's faces/s (an eight-wave kernel,
  *       csrc/encoder_heads_f16x2_w8.hip; layer 0 runs in two passes over x to make room for the second accumulator set).
  *       Packed image: NLML_MODE_F16X2's, 256 bytes, then a complete NLML_MODE_F32 image (the size still names the mode).
- *       Range behaviour: a tile with at most four faces beyond f16's range re-evaluates them itself as NLML_MODE_F16X2 does; a tile
- *       with MORE is re-evaluated whole on the f32 matrix cores from the f32 image by a second launch that the forward entry points
- *       enqueue behind the kernel (csrc/encoder_heads.hip, re-evaluation mode; it ends at once for every other tile): the strict
- *       parity kernel's bits on those faces, and a batch in which EVERY face overflows runs 3x slower, not 40x.
+ *       Range behaviour: a tile with faces beyond f16's range is re-evaluated whole on the f32 matrix cores from the f32 image by a
+ *       second launch that the forward entry points enqueue behind the kernel (csrc/encoder_heads.hip, re-evaluation mode; it ends at
+ *       once for every other tile; only the out-of-range faces are written): the strict parity kernel's bits on those faces, and a
+ *       batch in which EVERY face overflows runs 3x slower, not 40x.
  * The forward entry points recognise the mode of a blob by its size.
  */
 #define NLML_MODE_F32   0

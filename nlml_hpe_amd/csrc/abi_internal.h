@@ -21,8 +21,10 @@ int launch_encoder_heads_f32(const float* x, int64_t ldx, const float* raw, int 
                              int reeval_over = -1);   // >= 0: re-evaluation launch behind a split-f16 one (encoder_heads.hip)
 // the f32 image inside an NLML_MODE_F16X2S blob (pack.cpp): byte offset from the blob's start
 size_t strict_f32_image_offset(int F);
-// faces of a tile the strict-fast kernels re-evaluate themselves (vector ALUs, four at a time); a tile with more goes to the f32 launch
-constexpr int STRICT_INKERNEL_RESCUE_MAX = 4;
+// faces of a tile the strict-fast kernels re-evaluate themselves on the vector ALUs (as NLML_MODE_F16X2 does); a tile with more goes
+// to the f32 re-evaluation launch.  0: every face beyond f16's range is re-evaluated on the f32 matrix cores -- one rule, one
+// accuracy class (the strict parity kernel's bits), and no slow-path code inside the strict kernels.
+constexpr int STRICT_INKERNEL_RESCUE_MAX = 0;
 // encoder_heads_bf16.hip (throughput mode)
 int launch_encoder_heads_bf16(const float* x, int64_t ldx, const float* raw, int normalize,
                               int64_t B, int F, const void* blob, float* out, float* latent,

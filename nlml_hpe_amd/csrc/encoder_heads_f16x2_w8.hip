@@ -414,7 +414,7 @@ int launch_encoder_heads_f16x2_w8(const float* x, int64_t ldx, const float* raw,
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
-  // tiles with more than STRICT_INKERNEL_RESCUE_MAX faces beyond f16's range: the whole tile again on the f32 matrix cores, from the
+  // tiles with faces beyond f16's range (more than STRICT_INKERNEL_RESCUE_MAX = 0 of them): the whole tile again on the f32 matrix cores, from the
   // f32 image behind the split-f16 one; every other tile of that launch ends after one 768-byte read (encoder_heads.hip)
   return launch_encoder_heads_f32(x, ldx, raw, normalize, B, F, static_cast<const char*>(blob) + strict_f32_image_offset(F), out, latent,
                                   nullptr, nullptr, nullptr, stream, STRICT_INKERNEL_RESCUE_MAX);
