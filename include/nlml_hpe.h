@@ -147,7 +147,7 @@ int nlml_landmarks_to_pose(const float* raw, int64_t B, int normalize,
  * 64-face video tick: 0.06 ms instead of 0.17 ms); the results are bit-identical to nlml_encoder_heads_fwd / nlml_landmarks_to_pose with the same blob.
  * Activations pass between the launches through `workspace` (device memory, 16-byte aligned, at least
  * nlml_encoder_heads_small_workspace_bytes(B, F) bytes, contents irrelevant before and after); stream order is the only
- * synchronisation, so the sequence can be captured into a hipGraph.  Above ~8,000 faces the fused entry points are faster.
+ * synchronisation, so the sequence can be captured into a hipGraph.  Above ~4,500 faces the fused entry points are faster.
  */
 size_t nlml_encoder_heads_small_workspace_bytes(int64_t B, int F);
 int nlml_encoder_heads_fwd_small(const float* x, int64_t ldx, int64_t B, int F,

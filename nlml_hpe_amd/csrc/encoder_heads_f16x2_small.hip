@@ -18,6 +18,7 @@
 //   64*tile + 32*fb + (lane&31).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "../../include/nlml_hpe.h"
@@ -308,6 +309,134 @@ __global__ __launch_bounds__(256, 1) void tail_kernel(hx::Args a, const h8* __re
   hx::tail_stages<true, RESCUE_UP_TO>(c, a, row0, acc3, wr3, fbsel);
 }
 
+}  // namespace hxs
+namespace hx {
+// ---- the tail in TWO launches (NLML_MODE_F16X2S): E3, E4, E5 per (tile, face block), then the three heads as SEPARATE workgroups per
+// (tile, face block, head) -- the heads are independent chains of five short stages, so at 64 faces six CUs work where two did and the
+// tail's 13 sequential stages become 3 + 5 (tail 20.3 -> ~11 us at 64 faces).  The latent image (hi/lo f16, 32 rows x 112 bytes x 2
+// planes) passes through the workspace buffer E2 no longer needs.  Per accumulator the MFMAs are the fused kernel's in the fused
+// kernel's order (a head stage's jobs one at a time or three in lock step: the same chains), so the bits are the fused kernel's.
+// No slow path here: the strict mode's out-of-range faces go to the f32 re-evaluation launch behind the tail.
+constexpr int LAT_ROW_BYTES = S_LAT * 2, LAT_BLOCK_BYTES = 32 * LAT_ROW_BYTES;   // one plane of one face block: 3,584 B
+static_assert(LAT_ROW_BYTES % 16 == 0 && O_LAT % 16 == 0 && P_LAT % 16 == 0, "16-byte copies of the latent image");
+
+__global__ __launch_bounds__(256, 1) void tail_encoder_kernel(Args a, const h8* __restrict__ xin, int buf_steps, char* __restrict__ latws) {
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  const int tid = threadIdx.x;
+  Ctx c;
+  c.blob8 = reinterpret_cast<const h8*>(a.blob);
+  c.blob4 = reinterpret_cast<const f32x4*>(a.blob);
+  c.hdr = load_hdr(reinterpret_cast<const Header*>(a.blob));
+  c.lds = lds;
+  c.lane = tid & 63;
+  c.f = c.lane & 31;
+  c.h = c.lane >> 5;
+  c.wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = c.wv;
+  const int64_t tile = blockIdx.x >> 1, row0 = tile * TILE_FACES;
+  const int fb = blockIdx.x & 1, face0 = 32 * fb;
+  if (row0 + face0 >= a.B) return;                            // no live face in this block (whole workgroup leaves)
+  f32x16 acc3[1][1];
+  h8 wr3[ring_slots(1, 1)][1][2];
+  tail_pre_e3<true>(c, acc3, wr3);                            // E3's bias and first weights fly while the image is copied
+  const h8* src = xin + (size_t)tile * buf_steps * hxs::STEP_UNITS;
+  for (int i = tid; i < 16 * 128; i += 256) {                 // E2's output: 256 columns = 16 K steps, this face block
+    const int l = i & 63, piece = (i >> 6) & 1, step = i >> 7;
+    const int face = face0 + (l & 31), k = 16 * step + 8 * (l >> 5);
+    *reinterpret_cast<h8*>(lds + O_H3 + piece * P_H3 + (face * S_H3 + k) * 2) = src[(size_t)step * hxs::STEP_UNITS + (fb * 2 + piece) * 64 + l];
+  }
+  __syncthreads();
+  const bool do4 = wv < 2, do5 = wv == 0;                     // E4: neuron block wv (waves 0, 1); E5: wave 0
+  f32x16 acc4[1][1], acc5[2][1];
+  h8 wr4[6][1][2], wr5[6][2][2];
+  // ---- E3: 256 -> 128, ReLU
+  job_run<1, 1, ST_E3>(c, wv, acc3, wr3, O_H3, P_H3, S_H3, 0, face0);
+  job_store<1, 1, ACT_RELU>(c, acc3, O_H4, P_H4, S_H4, 32 * wv, face0, c.hdr.inv_scale[ST_E3], fetch_hook<2, 1, 1, ST_E4>(c, wv & 1, acc4, wr4));
+  __syncthreads();
+  // ---- E4: 128 -> 64, Tanh (every wave fetches, also the ones that do not run the stage: encoder_heads_f16x2_dev.h)
+  if (do4) job_run<1, 1, ST_E4>(c, wv & 1, acc4, wr4, O_H4, P_H4, S_H4, 0, face0);
+  job_pre<2, 1, ST_E5>(c, 0, acc5, wr5);
+  if (do4) job_store<1, 1, ACT_TANH>(c, acc4, O_H5, P_H5, S_H5, 32 * (wv & 1), face0, c.hdr.inv_scale[ST_E4]);
+  __syncthreads();
+  // ---- E5: 64 -> 9, latent n = 3g+c on row 16g+c (2 blocks), other rows exact zeros
+  if (do5) {
+    job_run<2, 1, ST_E5>(c, 0, acc5, wr5, O_H5, P_H5, S_H5, 0, face0);
+    const float inv = c.hdr.inv_scale[ST_E5];
+    if (a.latent && row0 + face0 + c.f < a.B) {               // f32 latent straight from the accumulators
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int rowi = 32 * nb + (q & 3) + 8 * (q >> 2) + 4 * c.h, g = rowi >> 4, cc = rowi & 15;
+          if (g < 3 && cc < 3) a.latent[(row0 + face0 + c.f) * NLML_LATENT + 3 * g + cc] = acc5[nb][0][q] * inv;
+        }
+    }
+    job_store<2, 1, ACT_NONE, S_LAT>(c, acc5, O_LAT, P_LAT, S_LAT, 0, face0, inv);
+  }
+  __syncthreads();
+  // the face block's rows of the latent image, both planes, to the workspace
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  char* dst = latws + ((size_t)tile * 2 + fb) * (2 * LAT_BLOCK_BYTES);
+  for (int i = tid; i < 2 * LAT_BLOCK_BYTES / 16; i += 256) {
+    const int piece = i / (LAT_BLOCK_BYTES / 16), o = (i % (LAT_BLOCK_BYTES / 16)) * 16;
+    *reinterpret_cast<u4*>(dst + piece * LAT_BLOCK_BYTES + o) = *reinterpret_cast<const u4*>(lds + O_LAT + piece * P_LAT + face0 * LAT_ROW_BYTES + o);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void head_kernel(Args a, const char* __restrict__ latws) {
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  const int tid = threadIdx.x;
+  Ctx cl;
+  cl.blob8 = reinterpret_cast<const h8*>(a.blob);
+  cl.blob4 = reinterpret_cast<const f32x4*>(a.blob);
+  cl.hdr = load_hdr(reinterpret_cast<const Header*>(a.blob));
+  cl.lds = lds;
+  cl.lane = tid & 63;
+  cl.f = cl.lane & 31;
+  cl.h = cl.lane >> 5;
+  cl.wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = cl.wv;
+  const int g = blockIdx.x % 3, fb = (blockIdx.x / 3) & 1, face0 = 32 * fb;
+  const int64_t tile = blockIdx.x / 6, row0 = tile * TILE_FACES;
+  if (row0 + face0 >= a.B) return;
+  const int job = 4 * g + wv;
+  f32x16 acc0[1][1], acc1[2][1], acc2[1][1], acc3[1][1], acc4[1][1];
+  h8 wr0[6][1][2], wr1[6][2][2], wr2[6][1][2], wr3[6][1][2], wr4[6][1][2];
+  job_pre<1, 1, ST_H0>(cl, job, acc0, wr0);                   // H0's operands fly while the latent image is copied in
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const char* src = latws + ((size_t)tile * 2 + fb) * (2 * LAT_BLOCK_BYTES);
+  for (int i = tid; i < 2 * LAT_BLOCK_BYTES / 16; i += 256) {
+    const int piece = i / (LAT_BLOCK_BYTES / 16), o = (i % (LAT_BLOCK_BYTES / 16)) * 16;
+    *reinterpret_cast<u4*>(lds + O_LAT + piece * P_LAT + face0 * LAT_ROW_BYTES + o) = *reinterpret_cast<const u4*>(src + piece * LAT_BLOCK_BYTES + o);
+  }
+  __syncthreads();
+  // H0_g: 3 -> 128 (K padded to 16), ReLU; wave = neuron block
+  job_run<1, 1, ST_H0>(cl, job, acc0, wr0, O_LAT, P_LAT, S_LAT, 16 * g, face0);
+  job_store<1, 1, ACT_RELU>(cl, acc0, O_GA, P_G128, S_G128, 32 * wv, face0, cl.hdr.inv_scale[ST_H0], fetch_hook<2, 2, 1, ST_H1>(cl, job, acc1, wr1));
+  __syncthreads();
+  // H1_g: 128 -> 256, ReLU; wave = two neuron blocks
+  job_run<2, 1, ST_H1>(cl, job, acc1, wr1, O_GA, P_G128, S_G128, 0, face0);
+  job_store<2, 1, ACT_RELU>(cl, acc1, O_GB, P_G256, S_G256, 64 * wv, face0, cl.hdr.inv_scale[ST_H1], fetch_hook<4, 1, 1, ST_H2>(cl, job, acc2, wr2));
+  __syncthreads();
+  // H2_g: 256 -> 128, ReLU; its output image lies over HA_g (dead since the barrier above)
+  job_run<1, 1, ST_H2>(cl, job, acc2, wr2, O_GB, P_G256, S_G256, 0, face0);
+  job_store<1, 1, ACT_RELU>(cl, acc2, O_GC, P_G128, S_G128, 32 * wv, face0, cl.hdr.inv_scale[ST_H2], fetch_hook<2, 1, 1, ST_H3>(cl, 2 * g + (wv & 1), acc3, wr3));
+  __syncthreads();
+  // H3_g: 128 -> 64, ReLU: two jobs, waves 0 and 1 (every wave fetches)
+  if (wv < 2) job_run<1, 1, ST_H3>(cl, 2 * g + wv, acc3, wr3, O_GC, P_G128, S_G128, 0, face0);
+  job_pre<1, 1, ST_H4>(cl, g, acc4, wr4);
+  if (wv < 2) job_store<1, 1, ACT_RELU>(cl, acc3, O_GD, P_G64, S_G64, 32 * wv, face0, cl.hdr.inv_scale[ST_H3]);
+  __syncthreads();
+  // H4_g: 64 -> 1; neuron on accumulator row 0 = register 0 of lanes 0..31; wave 0
+  if (wv == 0) {
+    job_run<1, 1, ST_H4>(cl, g, acc4, wr4, O_GD, P_G64, S_G64, 0, face0);
+    const int face = face0 + cl.f;
+    if (cl.h == 0 && row0 + face < a.B) a.out[(row0 + face) * 3 + g] = acc4[0][0][0] * cl.hdr.inv_scale[ST_H4];
+  }
+}
+
+}  // namespace hx
+namespace hxs {
 static int e0_k16(int F) { return (F + 2 * hx::XS_COLS - 1) / (2 * hx::XS_COLS) * (2 * hx::XS_STEPS); }   // as pack.cpp
 
 }  // namespace hxs
@@ -391,8 +520,15 @@ int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* r
     hx::Args ta{};
     ta.B = B; ta.F = F; ta.blob = blob; ta.out = out; ta.latent = latent; ta.valid = nullptr;
     ta.x = src; ta.ldx = sld; ta.norm = raw ? (normalize ? 1 : 0) : 0;   // the tail's slow path re-reads the face's input
-    if (split) hipLaunchKernelGGL(tail_kernel<STRICT_INKERNEL_RESCUE_MAX>, dim3((unsigned)(2 * ntiles)), dim3(256), 0, st, ta, (const h8*)in, buf_steps);
-    else hipLaunchKernelGGL(tail_kernel<64>, dim3((unsigned)(2 * ntiles)), dim3(256), 0, st, ta, (const h8*)in, buf_steps);
+    static const bool tail_one = [] { const char* e = getenv("NLML_K2_SMALL_TAIL1"); return e && e[0] == '1'; }();   // A/B: the one-launch tail
+    if (split && !tail_one) {   // E3..E5, then the three heads as workgroups of their own; the latent image passes through the free buffer
+      hipLaunchKernelGGL(hx::tail_encoder_kernel, dim3((unsigned)(2 * ntiles)), dim3(256), 0, st, ta, (const h8*)in, buf_steps, reinterpret_cast<char*>(outb));
+      hipLaunchKernelGGL(hx::head_kernel, dim3((unsigned)(6 * ntiles)), dim3(256), 0, st, ta, reinterpret_cast<const char*>(outb));
+    } else if (split) {
+      hipLaunchKernelGGL(tail_kernel<STRICT_INKERNEL_RESCUE_MAX>, dim3((unsigned)(2 * ntiles)), dim3(256), 0, st, ta, (const h8*)in, buf_steps);
+    } else {
+      hipLaunchKernelGGL(tail_kernel<64>, dim3((unsigned)(2 * ntiles)), dim3(256), 0, st, ta, (const h8*)in, buf_steps);
+    }
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));

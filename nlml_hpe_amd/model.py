@@ -73,7 +73,8 @@ class HIPPoseModel:
                    return_latent=return_latent, return_valid=return_valid)
 
     SMALL_BATCH_MAX = 4096          # NLML_MODE_F16X2: above this the fused kernel wins (5,120 faces: 0.140 against 0.159 ms)
-    SMALL_BATCH_MAX_STRICT = 8192   # NLML_MODE_F16X2S: its fused kernel is slower per tile (8,192 faces: 0.201 against 0.192 ms layered)
+    SMALL_BATCH_MAX_STRICT = 4096   # NLML_MODE_F16X2S: with the eight-wave fused kernel the same crossover (5,120 faces: 0.152 against 0.159 ms
+                                    # layered; 4,096: 0.152 against 0.123; round 3's four-wave kernel lost up to 8,192)
 
     @classmethod
     def small_batch_max(cls, mode) -> int:
