@@ -52,6 +52,8 @@ __device__ __forceinline__ double div_ipd(double n, double d, double y) {
 
 // ---- pre-pass: x (f32 rows, or raw landmarks with optional IPD normalisation) -> hi/lo fragments of layer 0's input.
 // One wave per face; lane handles 8-column chunks c = lane, lane + 64, ... (chunk c = K step c/2, half c&1).
+// VEC4: F, the row stride and the base address allow 16-byte loads (the shipped 1,404-column rows do).
+template <bool VEC4>
 __global__ __launch_bounds__(256) void prepass_kernel(const float* __restrict__ x, int64_t ldx, int64_t B, int F, int norm,
                                                       int k16, int buf_steps, h8* __restrict__ ws,
                                                       uint8_t* __restrict__ valid) {
@@ -61,6 +63,17 @@ __global__ __launch_bounds__(256) void prepass_kernel(const float* __restrict__ 
   const int fi = (int)(face & 63), fb = fi >> 5, f = fi & 31;
   const bool live = face < B;
   const float* p = x + (live ? face : B - 1) * ldx;
+  f32x4 q[3][2];   // the trip's chunks as loaded
+  auto loadq = [&](int c0) {   // branch-free: an address clamped into the row (the value is zeroed where it lay outside)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int k = 8 * (c0 + 64 * i) + 4 * hh;
+        q[i][hh] = *reinterpret_cast<const f32x4*>(p + (k < F ? k : F - 4));
+      }
+  };
+  if (VEC4) loadq(lane);   // before the reference points: in flight while the reciprocal is formed
   double ipd = 1.0, rcp = 1.0, ref0 = 0.0, ref1 = 0.0, ref2 = 0.0;
   if (norm) {   // FeatureExtractor.py:30-66, exactly as K1 and the fused kernels do it
     const double dx = (double)p[99] - (double)p[789], dy = (double)p[100] - (double)p[790], dz = (double)p[101] - (double)p[791];
@@ -70,30 +83,54 @@ __global__ __launch_bounds__(256) void prepass_kernel(const float* __restrict__ 
     ref0 = (double)p[3]; ref1 = (double)p[4]; ref2 = (double)p[5];
   }
   unsigned nz = 0u;
-  for (int c = lane; c < 2 * k16; c += 64) {
-    float v[8];
+  // Three chunks per lane and trip (layer 0 of the shipped encoder: 176 chunks = one trip): their 24 loads are issued together with the
+  // reference-point loads above, so the wave pays ONE memory latency, not one per chunk after the reciprocal's (64 faces: 8.1 -> us).
+  for (int c0 = lane; c0 < 2 * k16; c0 += 192) {
+    float v[3][8];
+    if (VEC4) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = 8 * c + e;
-      float t = k < F ? p[k] : 0.0f;
-      const int ph = k % 3;
-      if (norm && k < F) t = (float)div_ipd((double)t - (ph == 0 ? ref0 : (ph == 1 ? ref1 : ref2)), ipd, rcp);
-      v[e] = t;
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int k = 8 * (c0 + 64 * i) + 4 * hh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[i][4 * hh + e] = k < F ? q[i][hh][e] : 0.0f;
+        }
+      if (c0 + 192 < 2 * k16) loadq(c0 + 192);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = 8 * (c0 + 64 * i) + e;
+          v[i][e] = k < F ? p[k] : 0.0f;
+        }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(v[e]));   // keep the f32 value (see encoder_heads_f16x2.hip)
-    h8 hi, lo;
+    for (int i = 0; i < 3; ++i) {
+      const int c = c0 + 64 * i;
+      if (c >= 2 * k16) break;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      nz |= __float_as_uint(v[e]) & 0x7fffffffu;
-      const _Float16 hv = (_Float16)v[e];
-      hi[e] = hv;
-      lo[e] = (_Float16)(v[e] - (float)hv);
-    }
-    if (live) {
-      h8* d = ws + ((size_t)tile * buf_steps + (c >> 1)) * STEP_UNITS + (size_t)(fb * 2) * 64 + f + 32 * (c & 1);
-      d[0] = hi;
-      d[64] = lo;
+      for (int e = 0; e < 8; ++e) {
+        const int k = 8 * c + e;
+        const int ph = k % 3;
+        if (norm && k < F) v[i][e] = (float)div_ipd((double)v[i][e] - (ph == 0 ? ref0 : (ph == 1 ? ref1 : ref2)), ipd, rcp);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(v[i][e]));   // keep the f32 value (see encoder_heads_f16x2.hip)
+      h8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        nz |= __float_as_uint(v[i][e]) & 0x7fffffffu;
+        const _Float16 hv = (_Float16)v[i][e];
+        hi[e] = hv;
+        lo[e] = (_Float16)(v[i][e] - (float)hv);
+      }
+      if (live) {
+        h8* d = ws + ((size_t)tile * buf_steps + (c >> 1)) * STEP_UNITS + (size_t)(fb * 2) * 64 + f + 32 * (c & 1);
+        d[0] = hi;
+        d[64] = lo;
+      }
     }
   }
   const unsigned long long any = __ballot(nz != 0u);
@@ -116,13 +153,18 @@ struct LayerArgs {
 // R = depth of the operand ring.  With few units (one wave per CU) a unit's rate is its own loads in flight, so those
 // launches use 64-thread workgroups (the units spread over the CUs instead of sharing one four at a time) and R = 8.
 // SPLITK != 0: the small products of a K step accumulate apart, as the fused kernel's step_fine does for this layer in the blob's mode.
-template <int NBW, int R, int SPLITK>
+// NFB = face blocks per unit: 2 (a weight fragment feeds both face blocks), or 1 for the smallest batches -- a unit is then (tile, job,
+// group, face block): twice the waves, each streaming 4 KiB instead of 6 per K step (a wave alone on a CU is bound by its own stream:
+// layer 0 at 64 faces 14.0 -> 9.5 us), the weights fetched twice chip-wide.  Faces are MFMA columns: the same bits either way.
+template <int NBW, int R, int SPLITK, int NFB = 2>
 __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
   constexpr bool SPLIT = SPLITK != 0;   // SPLITK: 0 = single accumulators, 1 = split accumulators, 2 = split from K step a.split_from on
   const int lane = threadIdx.x & 63, f = lane & 31, h = lane >> 5;
-  const int groups = a.nb_stage / NBW;                     // units per (tile, job)
-  const int64_t u = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (u >= (int64_t)a.ntiles * a.jobs * groups) return;    // whole wave leaves together
+  const int groups = a.nb_stage / NBW;                     // units per (tile, job) and face-block choice
+  int64_t u = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (u >= (int64_t)a.ntiles * a.jobs * groups * (2 / NFB)) return;    // whole wave leaves together
+  const int fb0 = NFB == 1 ? (int)(u & 1) : 0;             // the unit's (first) face block
+  if (NFB == 1) u >>= 1;
   const int grp = (int)(u % groups), job = (int)((u / groups) % a.jobs);
   const int64_t tile = u / ((int64_t)groups * a.jobs);
   const int nb0 = grp * NBW;
@@ -131,7 +173,7 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
   const f32x4* blob4 = reinterpret_cast<const f32x4*>(a.blob);
   const int st = a.stage, NBS = a.nb_stage, K16 = a.K16;
 
-  f32x16 acc[NBW][2];
+  f32x16 acc[NBW][NFB];
   {  // bias in accumulator-register order (layout.h), scaled like the weights
     const f32x4* b = blob4 + hdr->b_off[st] + (size_t)job * (NBS * 8);
 #pragma unroll
@@ -140,7 +182,7 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
       for (int q = 0; q < 4; ++q) {
         const f32x4 v = b[((nb0 + i) * 2 + h) * 4 + q];
 #pragma unroll
-        for (int fb = 0; fb < 2; ++fb) {
+        for (int fb = 0; fb < NFB; ++fb) {
           acc[i][fb][4 * q + 0] = v[0]; acc[i][fb][4 * q + 1] = v[1];
           acc[i][fb][4 * q + 2] = v[2]; acc[i][fb][4 * q + 3] = v[3];
         }
@@ -150,7 +192,7 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
   const h8* xi = a.xin + ((size_t)tile * a.buf_steps + a.in_step0[job]) * STEP_UNITS + lane;          // + step*256
 
   constexpr int D = R - 1;
-  h8 wr[R][NBW][2], xr[R][2][2];
+  h8 wr[R][NBW][2], xr[R][NFB][2];
   auto load = [&](int slot, int s) {
     const h8* wp = w + (size_t)s * NBS * 128;
 #pragma unroll
@@ -159,16 +201,16 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
       for (int p = 0; p < 2; ++p) wr[slot][i][p] = wp[(i * 2 + p) * 64];
     const h8* xp = xi + (size_t)s * STEP_UNITS;
 #pragma unroll
-    for (int fb = 0; fb < 2; ++fb)
+    for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-      for (int p = 0; p < 2; ++p) xr[slot][fb][p] = xp[(fb * 2 + p) * 64];
+      for (int p = 0; p < 2; ++p) xr[slot][fb][p] = xp[((fb0 + fb) * 2 + p) * 64];
   };
   constexpr int NBS_ = SPLIT ? NBW : 1;
-  f32x16 accS[NBS_][2];   // the two small products of every K step; added to acc at the end (layer 1: also at its K midpoint,
+  f32x16 accS[NBS_][NFB];   // the two small products of every K step; added to acc at the end (layer 1: also at its K midpoint,
 #pragma unroll          // where the fused kernel parks layer 1's accumulators in LDS for the length of layer 0's second pass)
   for (int i = 0; i < NBS_; ++i)
 #pragma unroll
-    for (int fb = 0; fb < 2; ++fb)
+    for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
       for (int q = 0; q < 16; ++q) accS[i][fb][q] = 0.0f;
   auto fold = [&](bool clear) {
@@ -176,7 +218,7 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
 #pragma unroll
     for (int i = 0; i < NBS_; ++i)
 #pragma unroll
-      for (int fb = 0; fb < 2; ++fb) {
+      for (int fb = 0; fb < NFB; ++fb) {
         acc[i][fb] += accS[i][fb];
         if (clear) {
 #pragma unroll
@@ -193,7 +235,7 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
 #pragma unroll
       for (int i = 0; i < NBW; ++i)
 #pragma unroll
-        for (int fb = 0; fb < 2; ++fb)
+        for (int fb = 0; fb < NFB; ++fb)
           // split accumulators, exactly as the fused kernel (encoder_heads_f16x2_dev.h step_fine): small products apart
           if (SP && t < 2) accS[SP ? i : 0][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[slot][i][wp_], xr[slot][fb][xp_], accS[SP ? i : 0][fb], 0, 0, 0);
           else acc[i][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[slot][i][wp_], xr[slot][fb][xp_], acc[i][fb], 0, 0, 0);
@@ -256,7 +298,7 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
 #pragma unroll
   for (int i = 0; i < NBW; ++i)
 #pragma unroll
-    for (int fb = 0; fb < 2; ++fb)
+    for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = a.out_col0[job] + 32 * (nb0 + i) + 8 * q + 4 * h;   // this lane's 4 neurons n .. n+3
@@ -268,7 +310,7 @@ __global__ __launch_bounds__(256) void layer_kernel(LayerArgs a) {
           hi[e] = hv;
           lo[e] = (_Float16)(v - (float)hv);
         }
-        h8* frag = a.xout + ((size_t)tile * a.buf_steps + (n >> 4)) * STEP_UNITS + (size_t)(fb * 2) * 64 + f + 32 * ((n >> 3) & 1);
+        h8* frag = a.xout + ((size_t)tile * a.buf_steps + (n >> 4)) * STEP_UNITS + (size_t)((fb0 + fb) * 2) * 64 + f + 32 * ((n >> 3) & 1);
         _Float16* d = reinterpret_cast<_Float16*>(frag) + (n & 7);
         *reinterpret_cast<h4*>(d) = hi;
         *reinterpret_cast<h4*>(d + 64 * 8) = lo;
@@ -464,8 +506,13 @@ int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* r
 
   const float* src = raw ? raw : x;
   const int64_t sld = raw ? NLML_F_REFERENCE : ldx;
-  hipLaunchKernelGGL(prepass_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, src, sld, B, F, raw ? (normalize ? 1 : 0) : 0,
-                     k16, buf_steps, bufA, valid);
+  const bool vec4 = F % 4 == 0 && F >= 4 && sld % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+  if (vec4)
+    hipLaunchKernelGGL(prepass_kernel<true>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, src, sld, B, F,
+                       raw ? (normalize ? 1 : 0) : 0, k16, buf_steps, bufA, valid);
+  else
+    hipLaunchKernelGGL(prepass_kernel<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, src, sld, B, F,
+                       raw ? (normalize ? 1 : 0) : 0, k16, buf_steps, bufA, valid);
 
   // the three big layers: {stage, K16, blocks per job, jobs}; ReLU; job j covers output columns 32 * blocks * j ..
   struct S { int stage, K16, nb, jobs; };
@@ -502,7 +549,14 @@ int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* r
     constexpr int kMinUnits = 2048;   // measured: 8 waves per CU keep enough loads in flight (256 units: 153 us at B = 2,000; 2,048: 114 us)
     while (nbw > 1 && (int64_t)ntiles * a.jobs * (a.nb_stage / nbw) < kMinUnits) nbw >>= 1;
     const int64_t units = (int64_t)ntiles * a.jobs * (a.nb_stage / nbw);
-    if (units < 1024) {   // fewer than four waves per CU: one wave per workgroup, deep ring
+    static const bool fb_units = [] { const char* e = getenv("NLML_K2_SMALL_FB2"); return !(e && e[0] == '1'); }();   // A/B: =1 keeps both face blocks in a unit
+    static const int fb_max = [] { const char* e = getenv("NLML_K2_SMALL_FBU"); return e ? atoi(e) : 256; }();
+    if (fb_units && nbw == 1 && units <= fb_max) {   // at most one wave per CU even so: one unit per (.., face block), see layer_kernel
+      const dim3 grid((unsigned)(2 * units)), block(64);
+      if (!use_split) hipLaunchKernelGGL((layer_kernel<1, 8, 0, 1>), grid, block, 0, st, a);
+      else if (a.split_from == 0) hipLaunchKernelGGL((layer_kernel<1, HXS_RS1, 1, 1>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((layer_kernel<1, 8, 2, 1>), grid, block, 0, st, a);
+    } else if (units < 1024) {   // fewer than four waves per CU: one wave per workgroup, deep ring
       const dim3 grid((unsigned)units), block(64);
       if (nbw == 4) hipLaunchKernelGGL((layer_kernel<4, 6, 0>), grid, block, 0, st, a);   // (four blocks per wave: layer 0 without a second set only)
       else if (nbw == 2) NLML_HXS_LAUNCH(2, 8, HXS_RS1);

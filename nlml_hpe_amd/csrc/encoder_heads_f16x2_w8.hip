@@ -70,7 +70,6 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
   constexpr int WSTEP = 4 * 2 * 64;                 // a layer-0 job has four blocks x two pieces per K step
   const int F = a.F;
   const int nslab = (int)c.hdr.k8_e0 / XS_STEPS;   // even (pack.cpp)
-  constexpr int SLAB_BYTES = 2 * P_XS;
 
   const int srow = tid >> 3, scol = (tid & 7) * 4;
   int64_t r = row0 + srow;
@@ -116,17 +115,6 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
     const int t = q % 3;
     const double rr = t == 0 ? ra : (t == 1 ? rb : rc);
     st.v[q] = (float)div_ipd_w8((double)st.v[q] - rr, ipd, rcp);
-  };
-  double nA = 0.0, nB = 0.0, qA = 0.0, qB = 0.0;   // the pair in flight
-  auto lw_norm2 = [&](Set& st, int pair, int link) {   // elements 2*pair, 2*pair+1 (static), link 0..5 of the division's chain
-    const int e0 = 2 * pair, e1 = e0 + 1;
-    const double r0 = e0 % 3 == 0 ? ra : (e0 % 3 == 1 ? rb : rc), r1 = e1 % 3 == 0 ? ra : (e1 % 3 == 1 ? rb : rc);
-    if (link == 0) { nA = (double)st.v[e0]; nB = (double)st.v[e1]; asm volatile("" : "+v"(nA), "+v"(nB)); }
-    if (link == 1) { nA = nA - r0; nB = nB - r1; asm volatile("" : "+v"(nA), "+v"(nB)); }
-    if (link == 2) { qA = nA * rcp; qB = nB * rcp; asm volatile("" : "+v"(qA), "+v"(qB)); }
-    if (link == 3) { nA = fma(-qA, ipd, nA); nB = fma(-qB, ipd, nB); asm volatile("" : "+v"(nA), "+v"(nB)); }
-    if (link == 4) { qA = fma(nA, rcp, qA); qB = fma(nB, rcp, qB); asm volatile("" : "+v"(qA), "+v"(qB)); }
-    if (link == 5) { st.v[e0] = (float)qA; st.v[e1] = (float)qB; asm volatile("" : "+v"(st.v[e0]), "+v"(st.v[e1])); }
   };
   auto lw_rotate = [&]() {   // next slab: columns + 32 => phase + 2
     const double t0 = rc; rc = rb; rb = ra; ra = t0;
