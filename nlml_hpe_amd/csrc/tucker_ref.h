@@ -19,7 +19,8 @@
 // on columns t and t+768 (1404 of the 1536 lane slots live); passes of 2..8 evaluations deal (wave-column, half of the evaluations)
 // units so that every SIMD issues the same number of chains (see "BALANCED passes" at tucker_ref_pass).  Three waves per SIMD because the
 // waves of a SIMD do not advance together: the oldest takes every issue slot it can use, its siblings finish one after the other, and
-// the last one runs alone -- at the 4.8 cycles per instruction ONE wave sustains -- for 1/3 of the pass (1/2 with two waves).
+// the last one runs alone -- at the 4.8 cycles per instruction ONE wave sustains -- for 1/3 of the pass (1/2 with two waves); since
+// round 4 the waves lower their issue priority as they progress (s_setprio in the main loop), which keeps the three together.
 // What keeps the vector ALUs fed (round 3; the round-2 form -- 512 threads x 3 columns -- ran at 0.46 of the issue rate, this one
 // at 0.58 in a burst / 0.69 sustained, 0.63 / 0.74 with the balanced passes: DESIGN.md section 3 has the stamps and what bounds it now):
 //   * Wm rows come through a three-slot register ring, the loads of block (i,j,k)+2 issued before the arithmetic of block
@@ -251,6 +252,20 @@ __device__ __attribute__((noinline)) void tucker_ref_pass(const TuckerShared& sh
 #pragma unroll
       for (int n = 0; n < NE; ++n) fy[n] = fac[n * FS + 5 + j];
       const int b0 = (i * 3 + j) * 3;
+#ifndef TR_NO_PRIO
+      {  // Issue priority falls with progress (s_setprio takes an immediate: four levels).  The arbiter serves the OLDEST wave of a SIMD
+         // first, so its three waves finished one after the other and the last ran alone, at the 4.8 cycles per instruction one wave
+         // sustains, for a third of the pass (main loop by wave: 59.7 k / 101.8 k / 131.5 k ticks; -DTR_NO_PRIO).  A wave that is
+         // ahead now has the lower priority: it still fills the slots its siblings leave, but cannot run away -- only the last
+         // segment's imbalance is left, hence segments of 8, 4, 2 and 1 of the 15 (i, j) steps: 119.8 k / 122.6 k / 121.6 k ticks
+         // against 118.8 k of pure issue (135 rows x 44 chains x 5 operations x 4 cycles), the pass 143.3 k -> 132.5 k.
+        const int ij = i * 3 + j;
+        if (ij == 0) __builtin_amdgcn_s_setprio(3);
+        else if (ij == 8) __builtin_amdgcn_s_setprio(2);
+        else if (ij == 12) __builtin_amdgcn_s_setprio(1);
+        else if (ij == 14) __builtin_amdgcn_s_setprio(0);
+      }
+#endif
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
 #ifndef TR_ABL_NOLOAD
