@@ -825,7 +825,7 @@ def test_fx9_td_gradient_on_device(tucker_art, golden_dir, device):
 
 # ---- split-f16 mode, one launch per layer (small batches) ---------------------------------------------------------
 @pytest.mark.parametrize("hx", HX_MODES)
-@pytest.mark.parametrize("F,B", [(1404, 1), (1404, 64), (1404, 65), (1404, 200), (1404, 2000), (136, 77), (13, 5), (1407, 130)])
+@pytest.mark.parametrize("F,B", [(1404, 1), (1404, 64), (1404, 65), (1404, 200), (1404, 500), (1404, 2000), (136, 77), (13, 5), (1407, 130)])
 def test_small_batch_path_is_bit_identical_to_the_fused_kernel(F, B, hx, head_sds, device):
     """nlml_encoder_heads_fwd_small runs every layer as its own launch over (neuron blocks x tiles) with activations in a
     workspace; per output it issues the same MFMAs in the same order as the fused split-f16 kernel, so pose, latent and
@@ -841,6 +841,23 @@ def test_small_batch_path_is_bit_identical_to_the_fused_kernel(F, B, hx, head_sd
     assert torch.equal(a, b) and torch.equal(la, lb) and torch.equal(va, vb)
     ref = EH.forward_numpy(x, EH.Params(sd, head_sds), np.float64)
     assert np.degrees(np.abs(b.cpu().numpy() - ref).max()) <= POSE_TOL_DEG
+
+
+@pytest.mark.parametrize("hx", HX_MODES)
+def test_small_batch_path_strided_and_unaligned_rows(hx, head_sds, device):
+    """The layer-per-launch path's pre-pass has a 16-byte-load form (aligned base, stride and width multiples of four) and a scalar
+    form: both stage the same values, whatever the row stride and the start's alignment -- same bits as the fused kernel on the
+    same view, and as the contiguous copy."""
+    F = 1404
+    sd = synth.encoder_state_dict(F, seed=0)
+    blob = _blob_hx(sd, head_sds, device, hx)
+    xfull = torch.from_numpy(synth.features(150, F + 12, seed=6)).to(device)
+    for off in (8, 3):                                  # 32-byte offset, stride F + 12 (vector form); 12-byte offset (scalar form)
+        view = xfull[:, off:off + F]
+        a = ops.encoder_heads_fwd(view, blob, F)
+        b = ops.encoder_heads_fwd_small(view, blob, F)
+        c = ops.encoder_heads_fwd_small(view.contiguous(), blob, F)
+        assert torch.equal(a, b) and torch.equal(b, c)
 
 
 @pytest.mark.parametrize("F,B", [(1404, 300), (1404, 64), (136, 77), (13, 5), (1407, 130)])
