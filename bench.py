@@ -355,11 +355,11 @@ def main():
         achieved = B * FLOP_PER_FACE[F] / (kern_ms * 1e-3) / 1e12
         if args.mode in ("f16x2", "f16x2s"):
             peak = PEAK_F16_MFMA_TFLOPS
-            kernel = "k2s_* (pre, E0, E1, E2, tail: 5 launches)" if layered else "encoder_heads_f16x2_kernel<.., SPLIT=false> (four waves)"
+            kernel = "layer-per-launch path (pre-pass, E0, E1, E2, tail; in the strict mode the tail is two launches and the f32 re-evaluation launch follows)" if layered else "encoder_heads_f16x2_kernel<.., SPLIT=false> (four waves)"
             if args.mode == "f16x2s":
-                kernel = ("prepass + 3 x layer_kernel + tail_kernel + f32 re-evaluation launch (6 launches)" if layered else
-                          "encoder_heads_f16x2_w8_kernel (eight waves) + encoder_heads_f32_kernel in re-evaluation mode (ends at once where no tile "
-                          "has more than four faces beyond f16's range); kernel_ms covers both launches")
+                kernel = ("prepass + 3 x layer_kernel + tail_encoder_kernel + head_kernel + f32 re-evaluation launch (7 launches)" if layered else
+                          "encoder_heads_f16x2_w8_kernel (eight waves) + encoder_heads_f32_kernel in re-evaluation mode (a workgroup ends at once "
+                          "where its tile has no face beyond f16's range); kernel_ms covers both launches")
             roof_extra = {"executed_flop_per_launch": SPLIT_PRODUCTS * B * FLOP_PER_FACE[F],
                           "executed_frac": SPLIT_PRODUCTS * achieved / peak,
                           "note": "each algorithmic product runs as 3 f16 MFMA products (hi*hi + hi*lo + lo*hi, f32 accumulate); "

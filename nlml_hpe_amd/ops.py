@@ -297,7 +297,8 @@ def _small_workspace(B: int, F: int, device) -> torch.Tensor:
 
 def encoder_heads_fwd_small(x: torch.Tensor, blob: torch.Tensor, F: int, return_latent: bool = False,
                             return_valid: bool = False, workspace: torch.Tensor | None = None):
-    """encoder_heads_fwd for small batches (split-f16 blob only): five launches spread over the whole chip, bit-identical results."""
+    """encoder_heads_fwd for small batches (split-f16 blob only): one launch per big layer (five launches; seven with a strict blob: its
+    tail is two launches and the f32 re-evaluation launch follows) spread over the whole chip, bit-identical results."""
     _need_cuda(x, "x", torch.float32)
     _need_cuda(blob, "blob", torch.uint8)
     if x.dim() != 2 or x.shape[1] != F:
@@ -326,7 +327,8 @@ def encoder_heads_fwd_small(x: torch.Tensor, blob: torch.Tensor, F: int, return_
 
 def landmarks_to_pose_small(raw: torch.Tensor, blob: torch.Tensor, normalize: bool = True, return_latent: bool = False,
                             return_valid: bool = False, workspace: torch.Tensor | None = None):
-    """landmarks_to_pose for small batches (split-f16 blob only): five launches spread over the whole chip, bit-identical results."""
+    """landmarks_to_pose for small batches (split-f16 blob only): one launch per big layer (five launches; seven with a strict blob) spread
+    over the whole chip, bit-identical results."""
     _need_cuda(raw, "raw", torch.float32)
     _need_cuda(blob, "blob", torch.uint8)
     if raw.dim() != 3 or raw.shape[1:] != (468, 3):

@@ -915,7 +915,7 @@ def test_small_batch_path_landmarks_workspace_and_errors(hx, head_sds, device):
 @pytest.mark.parametrize("hx", HX_MODES)
 def test_model_dispatches_small_batches_and_graph_replays(hx, head_sds, device):
     """HIPPoseModel in split-f16 mode uses the small-batch path up to SMALL_BATCH_MAX faces (same bits either way), and
-    the five-launch sequence replays from a hipGraph."""
+    the launch sequence (five launches, seven in the strict mode) replays from a hipGraph."""
     from nlml_hpe_amd.model import HIPPoseModel
     sd = synth.encoder_state_dict(1404, seed=0)
     model = HIPPoseModel(sd, head_sds, device=device, mode=hx)
