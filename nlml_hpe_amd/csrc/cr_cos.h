@@ -138,4 +138,19 @@ NLML_CR_HD double cr_cos(double x) {
   return neg ? -v : v;
 }
 
+// float32(a * cos(t) + d) with the cos correctly rounded -- the f-vector entry as the reference rounds it (TD_Tester.py:25-28,37) --
+// without paying for the double-double chain (~450 dependent operations, 2 us of every Powell round) unless it can matter.  The
+// library cos is within 2 ulp, i.e. within 2^-51 absolute of the correctly rounded one (|cos| <= 1), so v = a * cos + d is within
+// |a| * 2^-51 + a few roundings of the value the slow path forms; if v - delta and v + delta round to the SAME float with
+// delta = (|a| + |v|) * 2^-46 (32 times that bound), so does the slow path's value (rounding is monotonic) and it is returned;
+// otherwise -- about once in 2^21 values, more often only where a * cos + d cancels -- the slow path decides.  NaN falls through.
+NLML_CR_HD float cr_f32_a_cos_d(double a, double t, double d) {
+  NLML_CR_STRICT
+  const double v = a * cos(t) + d;
+  const double delta = (fabs(a) + fabs(v)) * 0x1p-46;
+  const float lo = (float)(v - delta), hi = (float)(v + delta);
+  if (lo == hi) return lo;
+  return (float)(a * cr_cos(t) + d);
+}
+
 }  // namespace nlml

@@ -411,8 +411,8 @@ __device__ __forceinline__ void tucker_fvec(TuckerShared& sh, const ParT& par, c
 #pragma clang fp contract(off)   // numpy rounds b*w, + c, a*cos, + d separately (TD_Tester.py:25-28)
   if (tid < EV * 9) {
     const int e = tid / 9, a = (tid % 9) / 3;
-    const double v = cp4[0] * cr_cos(cp4[1] * par(e, a) + cp4[2]) + cp4[3];   // correctly rounded cos: cr_cos.h
-    sh.fvec[e][a][tid % 3] = (double)(float)v;
+    // float32(a * cos(b * w + c) + d) with the cos correctly rounded, by the library cos wherever that cannot change the float (cr_cos.h)
+    sh.fvec[e][a][tid % 3] = (double)cr_f32_a_cos_d(cp4[0], cp4[1] * par(e, a) + cp4[2], cp4[3]);
   }
   __syncthreads();
 }
