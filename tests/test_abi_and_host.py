@@ -244,6 +244,31 @@ def test_cr_cos_is_correctly_rounded(tmp_path, repo_root):
         assert abs(Decimal(float(y[i])) - t) <= Decimal(float(np.spacing(abs(y[i])))) / 2, x[i]
 
 
+def test_f_vector_entry_fast_form_equals_the_correctly_rounded_one(tmp_path, repo_root):
+    """cr_f32_a_cos_d (csrc/cr_cos.h) returns float32(a * cos(t) + d) from the library cos wherever the float cannot depend on the
+    cos's last bits and from the double-double cos otherwise: the same float as the slow path alone on 3 M values -- random rows,
+    the shipped rows' ranges, and rows built to cancel (d = -a * cos(t0) with t next to t0), where the decision is closest."""
+    import ctypes as C
+    import subprocess
+    so = tmp_path / "crcos.so"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(so),
+                    os.path.join(repo_root, "tests", "native", "cr_cos_host.cpp")], check=True, capture_output=True, text=True)
+    lib = C.CDLL(str(so))
+    rng = np.random.default_rng(5)
+    n = 1_000_000
+    a = np.concatenate([rng.uniform(-12, 12, n), rng.uniform(-12, 12, n), rng.uniform(-12, 12, n)])
+    t = np.concatenate([rng.uniform(-10, 10, n), rng.uniform(-3.5, 3.5, n), rng.uniform(-3.5, 3.5, n)])
+    d = np.concatenate([rng.uniform(-12, 12, n), rng.uniform(-12, 12, n), np.zeros(n)])
+    t0 = t[2 * n:] + rng.uniform(-1e-7, 1e-7, n) * rng.integers(0, 2, n)       # half of them exactly at t: a * cos + d ~ 0
+    d[2 * n:] = -a[2 * n:] * np.cos(t0)
+    a[:4], t[:4], d[:4] = [1.0, 0.0, np.nan, 3.0], [np.nan, 1.0, 1.0, np.inf], [0.0, 0.0, 0.0, 1.0]
+    fast, slow = np.empty(len(a), np.float32), np.empty(len(a), np.float32)
+    P = lambda v: v.ctypes.data_as(C.c_void_p)
+    lib.cr_fvalue_arrays(P(a), P(t), P(d), P(fast), P(slow), C.c_long(len(a)))
+    assert np.array_equal(fast.view(np.uint32)[4:], slow.view(np.uint32)[4:])
+    assert np.isnan(fast[0]) and np.isnan(fast[2]) and np.isnan(fast[3]) and np.isnan(slow[0]) and fast[1] == slow[1] == 0.0
+
+
 def test_td_fast_order_checks_alignment_and_default_is_the_reference_order():
     """the matrix-core order reads Wm and x with 16-byte vector loads, so the ABI refuses a misaligned base or an
     ldx that is not a multiple of 4 in THAT order (the reference order, the default, reads dwords and accepts both).  The checks
