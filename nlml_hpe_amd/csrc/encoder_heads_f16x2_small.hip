@@ -550,8 +550,7 @@ int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* r
     while (nbw > 1 && (int64_t)ntiles * a.jobs * (a.nb_stage / nbw) < kMinUnits) nbw >>= 1;
     const int64_t units = (int64_t)ntiles * a.jobs * (a.nb_stage / nbw);
     static const bool fb_units = [] { const char* e = getenv("NLML_K2_SMALL_FB2"); return !(e && e[0] == '1'); }();   // A/B: =1 keeps both face blocks in a unit
-    static const int fb_max = [] { const char* e = getenv("NLML_K2_SMALL_FBU"); return e ? atoi(e) : 256; }();
-    if (fb_units && nbw == 1 && units <= fb_max) {   // at most one wave per CU even so: one unit per (.., face block), see layer_kernel
+    if (fb_units && nbw == 1 && units <= 256) {   // (wider thresholds, 512 .. 4,096 units, measured: no change)   // at most one wave per CU even so: one unit per (.., face block), see layer_kernel
       const dim3 grid((unsigned)(2 * units)), block(64);
       if (!use_split) hipLaunchKernelGGL((layer_kernel<1, 8, 0, 1>), grid, block, 0, st, a);
       else if (a.split_from == 0) hipLaunchKernelGGL((layer_kernel<1, HXS_RS1, 1, 1>), grid, block, 0, st, a);

@@ -26,5 +26,5 @@ for mode in (_lib.MODE_F16X2S, _lib.MODE_F16X2):
             e0.record(); ops.landmarks_to_pose_small(raw, blob, True); e1.record()
         torch.cuda.synchronize()
         ms = float(np.median([e0.elapsed_time(e1) for e0, e1 in evs]))
-        print(f"fb2={os.environ.get('NLML_K2_SMALL_FB2', '0')} fbu={os.environ.get('NLML_K2_SMALL_FBU', '256')} mode={mode} B={B}: {ms * 1e3:.1f} us per call, layered == fused: {same}", flush=True)
+        print(f"fb2={os.environ.get('NLML_K2_SMALL_FB2', '0')} mode={mode} B={B}: {ms * 1e3:.1f} us per call, layered == fused: {same}", flush=True)
 print("SMALL_FB", "PASS" if ok else "FAIL")
