@@ -1,5 +1,6 @@
-// encoder_heads_f16x2.hip -- K2 on the f16 matrix cores: the split-f16 mode (NLML_MODE_F16X2, the fast default) and the strict-fast mode
-// (NLML_MODE_F16X2S: the same operands and instructions with split accumulators, template parameter SPLIT; see the kernel's comment).
+// encoder_heads_f16x2.hip -- K2 on the f16 matrix cores: the four-wave kernel of the opt-in fast mode (NLML_MODE_F16X2).  The default
+// strict-fast mode (NLML_MODE_F16X2S: the same operands and instructions with split accumulators throughout) runs on the eight-wave
+// kernel of encoder_heads_f16x2_w8.hip; both share encoder_heads_f16x2_dev.h.
 //
 // Same network, stages and jobs as the f32 parity kernel (encoder_heads.hip; reference:
 // NLML_HPE_Model_Builder.py:33-53,76-92,115-126) and the same <=1e-4 degree bar, but the contraction runs on
@@ -20,14 +21,13 @@
 // values lose nothing beyond an absolute 2^-25.
 //
 // Structure: 64-face tiles, 4 waves; layer 0's 1024-wide output of 64 faces is 256 KB in hi+lo f16, so it reaches layer 1 in two
-// halves of 512 neurons, each followed by one K half of layer 1 (NLML_MODE_F16X2: ONE pass over x on 256 accumulators per lane, the
-// second half waiting in registers; NLML_MODE_F16X2S: two passes over x of 128 + 128 accumulators, layer 1's parked in LDS meanwhile);
+// halves of 512 neurons, each followed by one K half of layer 1 (ONE pass over x on 256 accumulators per lane, the second half
+// waiting in registers; the eight-wave strict kernel: two passes over x of 128 + 128 accumulators, layer 1's parked in LDS meanwhile);
 // x is staged f32 -> (optional f64 IPD normalisation) -> hi/lo f16 through three rotating 32-column LDS slabs; every K step
 // issues ONE MFMA per slot with the step's fetches and the staging pieces spread behind them (step_fine); a stage's global
 // fetches ride in the previous stage's epilogue; the heads run one at a time over both face blocks (encoder_heads_f16x2_dev.h).
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
 
 #include "../../include/nlml_hpe.h"
 #include "abi_internal.h"
@@ -255,210 +255,11 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const Args& a, int64_t ro
 }
 
 // ------------------------------------------------------------------------------------------
-// One pass of layer 0: x[64,F] f32 -> (optional IPD normalisation in f64) -> hi/lo f16 -> three rotating LDS slabs of 32 columns;
-// this wave computes the 128 neurons of job 4 * pass + wave (4 blocks) for both face blocks, with SPLIT ACCUMULATORS (step_fine):
-// `acc` takes w_hi*x_hi, `accS` the two small products -- 256 accumulator registers per lane, the whole AGPR file, which is why
-// layer 0 runs in two passes of 512 neurons again (round 2 ran both halves in one pass on 256 single accumulators: x staged once
-// instead of twice, +3 % faces/s, but 1.10x (1.23x before layer 1's second half and layer 2 got split accumulators) the reference's distance from the exact result at the reference's operating range;
-// this form is 12 % inside it) and why layer 1's accumulators are parked in LDS meanwhile (the caller).
+// NLML_MODE_F16X2: layer 0 in one pass over x on single accumulators, so is layer 1's first K half (no register is free while layer
+// 0's second half waits); split accumulators from layer 1's second K half on.  (Until the end of round 4 a template parameter SPLIT
+// also made this kernel the strict-fast mode's -- two passes of layer 0 with split accumulators, layer 1's parked in LDS: the
+// eight-wave kernel of encoder_heads_f16x2_w8.hip computes the same bits 15 % faster and is the only strict-fast kernel now.)
 template <bool VEC4, bool NORM>
-__device__ __forceinline__ void stage_e0_pass(const Ctx& c, const Args& a, int64_t row0, int tid, int pass,
-                                              f32x16 (&acc)[4][2], f32x16 (&accS)[4][2]) {
-  constexpr int NB = 4, NFB = 2;
-  const int F = a.F;
-  const int nslab = (int)c.hdr.k8_e0 / XS_STEPS;   // even (pack.cpp)
-  constexpr int SLAB_BYTES = 2 * P_XS;
-
-  // staging role: row srow (0..63), 8 consecutive columns scol..scol+7 of every slab
-  const int srow = tid >> 2, scol = (tid & 3) * 8;
-  int64_t r = row0 + srow;
-  const bool live = r < a.B;
-  r = live ? r : a.B - 1;
-  const float* p = a.x + r * a.ldx;
-  // IPD normalisation (FeatureExtractor.py:30-66) in f64 exactly like K1 and the f32 kernel: the f32 value the
-  // reference feeds the network is reproduced bit for bit (div_ipd == IEEE f64 division for these operands).  A
-  // cheaper f32 form, (x - ref) * (1/ipd), is ~1.5 ulp off and that alone moved faces with a tiny IPD by up to
-  // 3e-4 degree (65,536 random faces), so it is not used.
-  double ipd = 1.0, rcp = 1.0, ra = 0.0, rb = 0.0, rc = 0.0;
-  if (NORM) {
-    const double dx = (double)p[99] - (double)p[789], dy = (double)p[100] - (double)p[790], dz = (double)p[101] - (double)p[791];
-    ipd = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
-    if (ipd == 0.0) ipd = 1e-6;
-    rcp = 1.0 / ipd;
-    const double x0 = (double)p[3], y0 = (double)p[4], z0 = (double)p[5];
-    const int ph = scol % 3;   // coordinate of this thread's first column; a slab later the phase is + 32 % 3 = + 2
-    ra = ph == 0 ? x0 : (ph == 1 ? y0 : z0);
-    rb = ph == 0 ? y0 : (ph == 1 ? z0 : x0);
-    rc = ph == 0 ? z0 : (ph == 1 ? x0 : y0);
-  }
-  unsigned nzbits = 0u;
-
-  // staging set: 8 consecutive columns of one row as scalars (each piece below touches single elements)
-  struct Set { float v[8]; };
-  auto gload_half = [&](int s, Set& st, int i) {   // columns scol + 4i .. + 3 of slab s
-    s = s < nslab ? s : nslab - 1;
-    const int k = s * XS_COLS + scol + 4 * i;
-    if (VEC4) {
-      const int kc = k < F ? k : (NORM ? k - 12 * ((k - F + 15) / 12) : F - 4);   // phase-preserving clamp
-      const f32x4 t = *reinterpret_cast<const f32x4*>(p + kc);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) st.v[4 * i + e] = t[e];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) st.v[4 * i + e] = p[k + e < F ? k + e : F - 1];
-    }
-  };
-  auto gload = [&](int s, Set& st) { gload_half(s, st, 0); gload_half(s, st, 1); };
-  // staging of one slab in pieces, one per free MFMA slot of the slab's two K steps (lwrite() = all of them, prologue)
-  auto lw_begin = [&](Set& st) {   // the set's loads must have landed: everything below consumes them
-#pragma unroll
-    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(st.v[e]));
-  };
-  // Normalisation = six DEPENDENT f64 instructions per element (convert, subtract, multiply, two correction fmas, convert).  A free
-  // slot carries ONE link of the chains of FOUR elements (tools/probes/mfma_f16_dp_probe.hip: independent f64 instructions hide in
-  // the shadow of a 32x32x16 f16 MFMA, a dependent chain does not); the next link of the same element comes two MFMAs later.
-  // lw_norm (prologue only) is the plain chain.
-  auto lw_norm = [&](Set& st, int q) {   // element q (static)
-    const int t = q % 3;
-    const double rr = t == 0 ? ra : (t == 1 ? rb : rc);
-    st.v[q] = (float)div_ipd((double)st.v[q] - rr, ipd, rcp);
-  };
-  double nn[4] = {0.0, 0.0, 0.0, 0.0}, qq[4] = {0.0, 0.0, 0.0, 0.0};   // the four elements in flight
-  auto lw_norm4 = [&](Set& st, int grp, int link) {   // elements 4*grp .. 4*grp+3 (static), link 0..5 of div_ipd's chain
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = 4 * grp + i;
-      const double r0 = e % 3 == 0 ? ra : (e % 3 == 1 ? rb : rc);
-      // (the empty asm pins each link to its slot: pure arithmetic is otherwise sunk towards its use, back into one cluster)
-      if (link == 0) { nn[i] = (double)st.v[e]; asm volatile("" : "+v"(nn[i])); }
-      if (link == 1) { nn[i] = nn[i] - r0; asm volatile("" : "+v"(nn[i])); }
-      if (link == 2) { qq[i] = nn[i] * rcp; asm volatile("" : "+v"(qq[i])); }
-      if (link == 3) { nn[i] = fma(-qq[i], ipd, nn[i]); asm volatile("" : "+v"(nn[i])); }
-      if (link == 4) { qq[i] = fma(nn[i], rcp, qq[i]); asm volatile("" : "+v"(qq[i])); }
-      if (link == 5) { st.v[e] = (float)qq[i]; asm volatile("" : "+v"(st.v[e])); }
-    }
-  };
-  auto lw_rotate = [&]() {   // next slab: columns + 32 => phase + 2
-    const double t0 = rc; rc = rb; rb = ra; ra = t0;
-  };
-  typedef unsigned u4 __attribute__((ext_vector_type(4)));
-  unsigned pend_hi[4], pend_lo[4];
-  auto lw_split = [&](Set& st, int j, bool real_slab) {   // elements 2j, 2j+1 -> packed hi/lo f16 pairs
-    const unsigned m = real_slab ? 0x7fffffffu : 0u;
-    // split2 takes the f32 VALUES (asm operands), so the compiler cannot fold (f16)(f32)double into one f64 -> f16 conversion
-    // as hipcc 7.2 does for the C form (~20 integer instructions per element and a different rounding)
-    nzbits |= (__float_as_uint(st.v[2 * j]) | __float_as_uint(st.v[2 * j + 1])) & m;
-    split2(st.v[2 * j], st.v[2 * j + 1], pend_hi[j], pend_lo[j]);
-  };
-  auto lw_store = [&](int buf_off, int piece) {
-    char* d = c.lds + O_XS + buf_off + (srow * S_XS + scol) * 2;
-    if (piece == 0) *reinterpret_cast<u4*>(d) = u4{pend_hi[0], pend_hi[1], pend_hi[2], pend_hi[3]};
-    else *reinterpret_cast<u4*>(d + P_XS) = u4{pend_lo[0], pend_lo[1], pend_lo[2], pend_lo[3]};
-  };
-  auto lwrite = [&](int buf_off, Set& st, bool real_slab) {
-    lw_begin(st);
-    if (NORM) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) lw_norm(st, q);
-      lw_rotate();
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) lw_split(st, j, real_slab);
-    lw_store(buf_off, 0);
-    lw_store(buf_off, 1);
-  };
-
-  const int job = 4 * pass + c.wv;
-  load_bias<NB, NFB>(acc, c.blob4 + c.hdr.b_off(ST_E0) + job * (NB * 8), c.h);
-  zero_acc<NB, NFB>(accS);
-  const h8* w = c.blob8 + c.hdr.w_off(ST_E0) + (size_t)job * c.hdr.job_w16(ST_E0) + c.lane;
-  auto wfrag = [&](int ks) { return w + (size_t)ks * (NB * 2 * 64); };   // K step ks of this job
-
-  // TWO staging register sets (8 floats per thread each), one per slab parity: slab s+2 is written to LDS during
-  // slab s from set[s & 1], which is refilled at once with the loads of slab s+4.  vmcnt counts in issue
-  // order, so a set must be older than every weight load still wanted in flight when it is waited for: two slabs
-  // (4 K steps, 32 weight loads) lie between its loads and its use, and in the prologue the sets are loaded BEFORE
-  // the weight ring so that the loop header sees the same distance on entry as on the back edge.
-  Set set[2];
-  constexpr int R0 = 4, D0 = R0 - 1;   // weight ring: K step ks in slot ks % 4 = 2 * (slab & 1) + step of the slab
-  static_assert(2 * XS_STEPS == R0, "two slabs == ring slots");
-  h8 wr[R0][NB][2];
-  gload(0, set[0]);
-  gload(1, set[1]);
-  lwrite(0, set[0], true);
-  gload(2, set[0]);
-  lwrite(SLAB_BYTES, set[1], true);
-  gload(3, set[1]);
-#pragma unroll
-  for (int d = 0; d < D0; ++d)
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int pp = 0; pp < 2; ++pp) wr[d][nb][pp] = wfrag(d)[(nb * 2 + pp) * 64];
-  __syncthreads();
-
-  const int lane_off = (c.f * S_XS + 8 * c.h) * 2;   // bytes
-  constexpr int FB = 32 * S_XS * 2;                  // face block stride inside a plane
-  h8 xr[2][NFB][2];
-#pragma unroll
-  for (int fb = 0; fb < NFB; ++fb)
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) xr[0][fb][pp] = *reinterpret_cast<const h8*>(c.lds + O_XS + lane_off + pp * P_XS + fb * FB);
-
-  int o0 = 0, o1 = SLAB_BYTES, o2 = 2 * SLAB_BYTES;   // buffers of slabs s, s+1, s+2
-  auto slab = [&](int s, auto par_c) {
-    constexpr int PAR = decltype(par_c)::value;
-    const char* xrow = c.lds + O_XS + o0 + lane_off;
-    const char* xnext = c.lds + O_XS + o1 + lane_off;
-    const bool real = s + 2 < nslab;
-#pragma unroll
-    for (int kk = 0; kk < XS_STEPS; ++kk) {
-      const int slot = 2 * PAR + kk;                        // == K step % 4: two slabs are exactly one turn of the ring
-      const int ks = s * XS_STEPS + kk;
-      step_fine<NB, NFB>(acc, accS, wr[slot], xr[kk & 1], wr[(slot + D0) % R0], wfrag(ks + D0), true,
-              [&](int fb, int pp) {                         // the next K step's x operands
-                xr[(kk + 1) & 1][fb][pp] = (kk + 1 < XS_STEPS)
-                                               ? *reinterpret_cast<const h8*>(xrow + pp * P_XS + fb * FB + 32 * (kk + 1))
-                                               : *reinterpret_cast<const h8*>(xnext + pp * P_XS + fb * FB);
-              },
-              [&](int m) {   // slab s+2's staging in the free (odd) slots of the slab's two K steps: 24 slots
-#ifdef HX_ABL_NOSTAGE
-                return;      // timing-only ablation (wrong results)
-#endif
-                if ((m & 1) == 0) return;
-                const int j = 12 * kk + (m >> 1);            // free slot 0..23 of this slab
-                // 12 normalisation slots (2 groups of four elements x 6 links), rotate, 4 splits, 2 LDS stores, 2 reloads
-                if (j == 0) lw_begin(set[PAR]);
-                if (NORM && j < 12) lw_norm4(set[PAR], j / 6, j % 6);
-                if (NORM && j == 12) lw_rotate();
-                if (j >= 13 && j < 17) lw_split(set[PAR], j - 13, real);
-                if (j == 17) lw_store(o2, 0);
-                if (j == 18) lw_store(o2, 1);
-                if (j == 19) gload_half(s + 4, set[PAR], 0);
-                if (j == 20) gload_half(s + 4, set[PAR], 1);
-              });
-    }
-#ifndef HX_ABL_NOBAR
-    __syncthreads();
-#endif
-    const int t0 = o0;   // rotate: (o0, o1, o2) <- (o1, o2, o0)
-    o0 = o1; o1 = o2; o2 = t0;
-  };
-  for (int s = 0; s < nslab; s += 2) {
-    slab(s, std::integral_constant<int, 0>{});
-    slab(s + 1, std::integral_constant<int, 1>{});
-  }
-  if (pass == 0 && a.valid) {  // all-zero feature row == "no face" (FeatureExtractor.py:105-106); 4 lanes share a row
-    const unsigned long long m = __ballot(nzbits != 0u);
-    if ((tid & 3) == 0 && live) a.valid[row0 + srow] = ((m >> (c.lane & 60)) & 0xFull) ? 1 : 0;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// SPLIT = false: NLML_MODE_F16X2, layer 0 in one pass over x on single accumulators, so are layer 1's first K half (no register
-//                is free while layer 0's second half waits); split accumulators from layer 1's second K half on (the fast mode);
-// SPLIT = true:  NLML_MODE_F16X2S, split accumulators (step_fine), layer 0 in two passes (the strict-fast mode).
-template <bool VEC4, bool NORM, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
 
@@ -477,7 +278,6 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
 
   f32x16 acc2[2][2];
   h8 wr2[ring_slots(2, 2)][2][2];
-  if constexpr (!SPLIT) {
   {  // E0 (one pass over x, both neuron halves) then the two K halves of E1
     f32x16 acc1[4][2];
     const h8* w1 = c.blob8 + c.hdr.w_off(ST_E1) + (size_t)wv * c.hdr.job_w16(ST_E1) + c.lane;
@@ -530,82 +330,18 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
     job_store<4, 2, ACT_RELU>(c, acc1, O_H2, P_H2, S_H2, 128 * wv, 0, c.hdr.inv_scale[ST_E1],
                               fetch_hook<16, 2, 2, ST_E2>(c, wv, acc2, wr2));
   }
-  } else {
-  {  // E0 (two passes of 512 neurons, split accumulators) interleaved with the two K halves of E1
-    const h8* w1 = c.blob8 + c.hdr.w_off(ST_E1) + (size_t)wv * c.hdr.job_w16(ST_E1) + c.lane;
-    const float inv0 = c.hdr.inv_scale[ST_E0];
-    // Layer 1's accumulators (neurons 128*wv .. +127, both face blocks).  Layer 0 holds 256 accumulator registers per lane, so
-    // this set is PARKED IN LDS while a layer-0 pass runs: the h1 half image is dead then, lane-private 16-byte pieces,
-    // conflict-free.  The loop body fetches and parks in BOTH passes, so that the set is dead during layer 0 on every path the
-    // compiler sees (with a fetch in pass B only it keeps 128 more registers alive through pass A and spills).
-    f32x16 acc1[4][2];
-    f32x4* const park = reinterpret_cast<f32x4*>(c.lds + O_H1H) + tid;   // piece i of this lane at park[256 * i]
-    static_assert(32 * 256 * 16 <= 2 * P_H1H, "the parked layer-1 accumulators fit the h1 half image");
-    load_bias<4, 2>(acc1, c.blob4 + c.hdr.b_off(ST_E1) + wv * (4 * 8), c.h);
-    auto park_acc1 = [&]() {
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            park[256 * ((nb * 2 + fb) * 4 + q)] = f32x4{acc1[nb][fb][4 * q], acc1[nb][fb][4 * q + 1], acc1[nb][fb][4 * q + 2], acc1[nb][fb][4 * q + 3]};
-    };
-    park_acc1();
-    HXS(0);
-    HXS_WALL(30);
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      {
-        f32x16 acc0[4][2], acc0s[4][2];
-        stage_e0_pass<VEC4, NORM>(c, a, row0, tid, pass, acc0, acc0s);
-        add_acc<4, 2>(acc0, acc0s);
-        HXS(1 + 4 * pass);
-        // layer 1's accumulators back from LDS before the h1 half image is (over)written
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-          for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const f32x4 t = park[256 * ((nb * 2 + fb) * 4 + q)];
-              acc1[nb][fb][4 * q] = t[0]; acc1[nb][fb][4 * q + 1] = t[1]; acc1[nb][fb][4 * q + 2] = t[2]; acc1[nb][fb][4 * q + 3] = t[3];
-            }
-        __syncthreads();
-        job_store<4, 2, ACT_RELU>(c, acc0, O_H1H, P_H1H, S_H1H, 128 * wv, 0, inv0);
-      }
-      __syncthreads();
-      HXS(2 + 4 * pass);
-      {  // layer 1 over this K half; its small products are added at the end of the half
-        f32x16 acc1s[4][2];
-        zero_acc<4, 2>(acc1s);
-        kloop<4, 2, 32>(acc1, acc1s, w1 + (size_t)pass * 32 * (4 * 2 * 64), c.lds + O_H1H + (c.f * S_H1H + 8 * c.h) * 2, P_H1H,
-                        32 * S_H1H * 2);
-        add_acc<4, 2>(acc1, acc1s);
-      }
-      HXS(3 + 4 * pass);
-      __syncthreads();   // H1H is free again (pass 0: for the parked set and pass 1's store; pass 1: for H2)
-      park_acc1();       // (after pass 1 nothing reads it back: 32 idle LDS writes)
-      HXS(4 + 4 * pass);
-    }
-    __syncthreads();     // the parked pieces of pass 1 are dead; H2 overwrites the region
-    // E2's global fetches (bias, first ring slots) ride in E1's epilogue (store_lds hook, encoder_heads_f16x2_dev.h)
-    job_store<4, 2, ACT_RELU>(c, acc1, O_H2, P_H2, S_H2, 128 * wv, 0, c.hdr.inv_scale[ST_E1],
-                              fetch_hook<16, 2, 2, ST_E2>(c, wv, acc2, wr2));
-  }
-  }
   __syncthreads();
   HXS(9);
   f32x16 acc3[1][2];
   h8 wr3[ring_slots(1, 2)][1][2];
   // E2: 512 -> 256, ReLU; h3 overwrites h2 => barrier between the K loop and the store
-  job_run_split<2, 2, ST_E2>(c, wv, acc2, wr2, O_H2, P_H2, S_H2, 0, 0);   // (both modes: split accumulators)
+  job_run_split<2, 2, ST_E2>(c, wv, acc2, wr2, O_H2, P_H2, S_H2, 0, 0);   // (split accumulators)
   __syncthreads();
   job_store<2, 2, ACT_RELU>(c, acc2, O_H3, P_H3, S_H3, 64 * wv, 0, c.hdr.inv_scale[ST_E2],
                             fetch_hook<8, 1, 2, ST_E3>(c, wv, acc3, wr3));
   __syncthreads();
   HXS(10);
-  tail_stages<false, SPLIT ? STRICT_INKERNEL_RESCUE_MAX : 64>(c, a, row0, acc3, wr3);
+  tail_stages<false, 64>(c, a, row0, acc3, wr3);
   HXS_WALL(31);
 }
 
@@ -614,11 +350,8 @@ __global__ __launch_bounds__(256, 1) void encoder_heads_f16x2_kernel(Args a) {
 int launch_encoder_heads_f16x2(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,
                                const void* blob, float* out, float* latent, uint8_t* valid, int split, void* stream) {
   if (B == 0) return 0;
-  // the strict-fast mode's production kernel has eight waves per workgroup (encoder_heads_f16x2_w8.hip; same bits); the four-wave
-  // instantiation below stays reachable for A/B timing: NLML_K2_STRICT_W4=1
-  const char* const w4env = getenv("NLML_K2_STRICT_W4");   // read per call: a test flips it inside one process
-  const bool strict_w4 = w4env && w4env[0] == '1';
-  if (split && !strict_w4) return launch_encoder_heads_f16x2_w8(x, ldx, raw, normalize, B, F, blob, out, latent, valid, stream);
+  // the strict-fast mode runs on the eight-wave kernel (encoder_heads_f16x2_w8.hip)
+  if (split) return launch_encoder_heads_f16x2_w8(x, ldx, raw, normalize, B, F, blob, out, latent, valid, stream);
   hx::Args a;
   a.B = B; a.F = F; a.blob = blob; a.out = out; a.latent = latent; a.valid = valid; a.norm = 0;
   if (raw) {
@@ -629,22 +362,15 @@ int launch_encoder_heads_f16x2(const float* x, int64_t ldx, const float* raw, in
   const bool vec4 = (F % 4 == 0) && (a.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
   const dim3 grid((unsigned)((B + TILE_FACES - 1) / TILE_FACES)), block(256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define NLML_HX_LAUNCH(V, N)                                                                                   \
-  do {                                                                                                          \
-    if (split) hipLaunchKernelGGL((hx::encoder_heads_f16x2_kernel<V, N, true>), grid, block, 0, st, a);         \
-    else hipLaunchKernelGGL((hx::encoder_heads_f16x2_kernel<V, N, false>), grid, block, 0, st, a);              \
-  } while (0)
   if (a.norm) {
-    if (vec4) NLML_HX_LAUNCH(true, true); else NLML_HX_LAUNCH(false, true);
+    if (vec4) hipLaunchKernelGGL((hx::encoder_heads_f16x2_kernel<true, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((hx::encoder_heads_f16x2_kernel<false, true>), grid, block, 0, st, a);
   } else {
-    if (vec4) NLML_HX_LAUNCH(true, false); else NLML_HX_LAUNCH(false, false);
+    if (vec4) hipLaunchKernelGGL((hx::encoder_heads_f16x2_kernel<true, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((hx::encoder_heads_f16x2_kernel<false, false>), grid, block, 0, st, a);
   }
-#undef NLML_HX_LAUNCH
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
-  if (split)   // (the four-wave strict instantiation, NLML_K2_STRICT_W4=1: the same f32 re-evaluation launch as behind the eight-wave kernel)
-    return launch_encoder_heads_f32(x, ldx, raw, normalize, B, F, static_cast<const char*>(blob) + strict_f32_image_offset(F), out, latent,
-                                    nullptr, nullptr, nullptr, stream, STRICT_INKERNEL_RESCUE_MAX);
   return 0;
 }
 

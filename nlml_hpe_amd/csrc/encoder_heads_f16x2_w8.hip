@@ -1,8 +1,9 @@
 // encoder_heads_f16x2_w8.hip -- the strict-fast mode (NLML_MODE_F16X2S) with EIGHT waves per workgroup (two per SIMD).
 //
-// Same network, blob, LDS images, jobs and -- per accumulator -- the same MFMA sequence as encoder_heads_f16x2_kernel<.., SPLIT = true>
-// (encoder_heads_f16x2.hip; reference: NLML_HPE_Model_Builder.py:33-53,76-92,115-126), so the results are bit-identical to it and to the
-// layer-per-launch path.  What changes is who computes what: a job of the trunk (layer 0: four neuron blocks; layer 1: four; layer 2:
+// Same network, blob, LDS images, jobs and -- per accumulator -- the same MFMA sequence as round 3's four-wave strict kernel (a SPLIT
+// instantiation of encoder_heads_f16x2.hip's kernel, tested bit-identical to this one and then deleted; reference:
+// NLML_HPE_Model_Builder.py:33-53,76-92,115-126) and as the layer-per-launch path, which the tests compare it with bit for bit.
+// What changed against the four-wave form is who computes what: a job of the trunk (layer 0: four neuron blocks; layer 1: four; layer 2:
 // two) is shared by a PAIR of waves, each taking half of its blocks with both face blocks.  Why:
 //   * split accumulators need 2 x (512 neurons x 64 faces) registers per layer-0 pass whatever the wave count; with four waves that is
 //     256 of a wave's 512 registers next to a 128-register weight ring, so layer 1's accumulators had to be parked and everything else
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(512) void encoder_heads_f16x2_w8_kernel(Args a) {
     const h8* w1 = c.blob8 + c.hdr.w_off(ST_E1) + (size_t)jw * c.hdr.job_w16(ST_E1) + (2 * nbh * 2) * 64 + c.lane;
     const float inv0 = c.hdr.inv_scale[ST_E0];
     // Layer 1's accumulators (neurons 128*jw + 64*nbh .. +63, both face blocks) are parked in LDS while a layer-0 pass runs (the h1
-    // half image is dead then; lane-private 16-byte pieces, conflict-free) -- the four-wave kernel's structure, at half the registers.
+    // half image is dead then; lane-private 16-byte pieces, conflict-free) -- round 3's four-wave strict kernel's structure, at half the registers.
     f32x16 acc1[2][2];
     f32x4* const park = reinterpret_cast<f32x4*>(c.lds + O_H1H) + tid;   // piece i of this lane at park[512 * i]
     static_assert(16 * 512 * 16 <= 2 * P_H1H, "the parked layer-1 accumulators fit the h1 half image");

@@ -861,27 +861,26 @@ def test_small_batch_path_strided_and_unaligned_rows(hx, head_sds, device):
 
 
 @pytest.mark.parametrize("F,B", [(1404, 300), (1404, 64), (136, 77), (13, 5), (1407, 130)])
-def test_strict_eight_wave_kernel_equals_the_four_wave_one(F, B, head_sds, device, monkeypatch):
-    """NLML_MODE_F16X2S runs on the eight-wave kernel (encoder_heads_f16x2_w8.hip: a trunk job shared by a pair of waves, waves 4-7
-    ending before the tail); the four-wave instantiation stays reachable through NLML_K2_STRICT_W4=1.  Per accumulator both issue the
-    same MFMAs in the same order: pose, latent and validity are the same bits -- from features (incl. widths that are not a multiple
-    of 4: the scalar staging path) and, at the reference width, from raw landmarks with the fused normalisation."""
+def test_strict_eight_wave_kernel_equals_the_layer_per_launch_path(F, B, head_sds, device):
+    """NLML_MODE_F16X2S runs on the eight-wave kernel (encoder_heads_f16x2_w8.hip: a trunk job shared by a pair of waves, layer 0 in
+    two passes with layer 1's accumulators parked in LDS, waves 4-7 ending before the tail).  The layer-per-launch path is an
+    independent implementation of the same MFMA order per accumulator (one wave per neuron block, operands streamed from global
+    memory, no LDS in the big layers): pose, latent and validity are the same bits -- from features (incl. widths that are not a
+    multiple of 4: the scalar staging path) and, at the reference width, from raw landmarks with the fused normalisation.  (Until
+    the end of round 4 this test compared the eight-wave kernel with the four-wave strict instantiation, which it replaced.)"""
     sd = synth.encoder_state_dict(F, seed=3)
     blob = _blob_hx(sd, head_sds, device, "f16x2s")
     x = synth.features(B, F, seed=9)
     x[3] = 0.0
     xt = torch.from_numpy(x).to(device)
-    monkeypatch.delenv("NLML_K2_STRICT_W4", raising=False)
     a = ops.encoder_heads_fwd(xt, blob, F, return_latent=True, return_valid=True)
-    raw = torch.from_numpy(synth.raw_landmarks(B, seed=4)).to(device) if F == 1404 else None
-    ar = ops.landmarks_to_pose(raw, blob, True, return_latent=True, return_valid=True) if raw is not None else None
-    monkeypatch.setenv("NLML_K2_STRICT_W4", "1")
-    b = ops.encoder_heads_fwd(xt, blob, F, return_latent=True, return_valid=True)
-    br = ops.landmarks_to_pose(raw, blob, True, return_latent=True, return_valid=True) if raw is not None else None
-    monkeypatch.delenv("NLML_K2_STRICT_W4")
+    b = ops.encoder_heads_fwd_small(xt, blob, F, return_latent=True, return_valid=True)
     for u, v in zip(a, b):
         assert torch.equal(u, v)
-    if raw is not None:
+    if F == 1404:
+        raw = torch.from_numpy(synth.raw_landmarks(B, seed=4)).to(device)
+        ar = ops.landmarks_to_pose(raw, blob, True, return_latent=True, return_valid=True)
+        br = ops.landmarks_to_pose_small(raw, blob, True, return_latent=True, return_valid=True)
         for u, v in zip(ar, br):
             assert torch.equal(u, v)
     ref = EH.forward_numpy(x, EH.Params(sd, head_sds), np.float64)
