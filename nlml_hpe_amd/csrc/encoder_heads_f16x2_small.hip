@@ -573,13 +573,10 @@ int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* r
     hx::Args ta{};
     ta.B = B; ta.F = F; ta.blob = blob; ta.out = out; ta.latent = latent; ta.valid = nullptr;
     ta.x = src; ta.ldx = sld; ta.norm = raw ? (normalize ? 1 : 0) : 0;   // the tail's slow path re-reads the face's input
-    static const bool tail_one = [] { const char* e = getenv("NLML_K2_SMALL_TAIL1"); return e && e[0] == '1'; }();   // A/B: the one-launch tail
-    if (split && !tail_one) {   // E3..E5, then the three heads as workgroups of their own; the latent image passes through the free buffer
+    if (split) {   // E3..E5, then the three heads as workgroups of their own; the latent image passes through the free buffer
       hipLaunchKernelGGL(hx::tail_encoder_kernel, dim3((unsigned)(2 * ntiles)), dim3(256), 0, st, ta, (const h8*)in, buf_steps, reinterpret_cast<char*>(outb));
       hipLaunchKernelGGL(hx::head_kernel, dim3((unsigned)(6 * ntiles)), dim3(256), 0, st, ta, reinterpret_cast<const char*>(outb));
-    } else if (split) {
-      hipLaunchKernelGGL(tail_kernel<STRICT_INKERNEL_RESCUE_MAX>, dim3((unsigned)(2 * ntiles)), dim3(256), 0, st, ta, (const h8*)in, buf_steps);
-    } else {
+    } else {   // (the fast mode keeps the one-launch tail: its out-of-range faces are redone inside it)
       hipLaunchKernelGGL(tail_kernel<64>, dim3((unsigned)(2 * ntiles)), dim3(256), 0, st, ta, (const h8*)in, buf_steps);
     }
   }
