@@ -31,7 +31,10 @@ trunk = (tr[:, :, 11] - tr[:, :, 0]).astype(np.float64)
 print(f"{path}: trunk cycles per tile (wave avg) {trunk.mean():,.0f}")
 for i, n in enumerate(names):
     m = d[:, :, i].mean()
-    e = f"   MFMA-pipe time of the SIMD's two waves {ideal[i]:,} ({ideal[i] / m * 100:.0f}% busy)" if i in ideal else ""
+    # busy = matrix-pipe time of the SIMD's two waves over the SLOWER wave class's time (waves w and w + 4 share a SIMD and the older
+    # one is served first: where a loop has no barrier inside, the stage lasts as long as waves 4-7 do, not as long as the average)
+    slow = d[:, :, i].mean(axis=0).max()
+    e = f"   MFMA-pipe time of the SIMD's two waves {ideal[i]:,} ({ideal[i] / slow * 100:.0f}% busy against the slower wave class)" if i in ideal else ""
     print(f"  {n:24s} {m:10,.0f}  {m / trunk.mean() * 100:5.1f}%{e}   per wave {[int(v) for v in d[:, :, i].mean(axis=0)]}")
 tail = (tl[:, :, 21] - tr[:, :4, 11]).astype(np.float64)
 print(f"tail (waves 0-3; E3 .. heads) {tail.mean():,.0f} cycles;  tile = {trunk.mean() + tail.mean():,.0f}")
