@@ -121,6 +121,65 @@ int nlml_landmarks_to_pose_small(const float* raw, int64_t B, int normalize, con
                                           ws_bytes, split, stream);
 }
 
+// ---- strict-fast mode, LARGE batches: 128-face tiles, one launch per big layer (encoder_heads_f16x2_wide.hip) ----------------
+static int check_wide(int64_t B, int F, const void* blob, size_t blob_bytes, const float* out) {
+  int mode = 0;
+  if (int rc = check_blob_args(B, F, blob, blob_bytes, out, &mode)) return rc;
+  if (mode != NLML_MODE_F16X2S) return fail(NLML_E_BADARG, "wide path: NLML_MODE_F16X2S blob only");
+  return 0;
+}
+
+int nlml_encoder_heads_fwd_wide(const float* x, int64_t ldx, int64_t B, int F, const void* blob, size_t blob_bytes,
+                                float* out, float* latent, uint8_t* valid, void* workspace, size_t ws_bytes, void* stream) {
+  if (int rc = check_wide(B, F, blob, blob_bytes, out)) return rc;
+  if (B > 0 && (!x || ldx < F)) return fail(NLML_E_BADARG, "encoder_heads: null x or ldx < F");
+  return launch_encoder_heads_f16x2_wide(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, workspace, ws_bytes, stream);
+}
+
+int nlml_landmarks_to_pose_wide(const float* raw, int64_t B, int normalize, const void* blob, size_t blob_bytes,
+                                float* out, float* latent, uint8_t* valid, void* workspace, size_t ws_bytes, void* stream) {
+  if (int rc = check_wide(B, NLML_F_REFERENCE, blob, blob_bytes, out)) return rc;
+  if (B > 0 && !raw) return fail(NLML_E_BADARG, "landmarks_to_pose: null raw");
+  return launch_encoder_heads_f16x2_wide(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, workspace,
+                                         ws_bytes, stream);
+}
+
+// ---- the forward with a caller-provided workspace: the fastest path for the batch size and the blob's mode -------------------------
+// (measured crossovers, tools/k2_crossover.py and bench.py extra.k2_batch_sweep)
+static const int64_t kSmallMax = 4096;     // split-f16 modes: up to here the layer-per-launch path over 64-face tiles
+static const int64_t kWideMin = 16384;     // NLML_MODE_F16X2S: from here the 128-face-tile path
+
+size_t nlml_encoder_heads_workspace_bytes(int64_t B, int F) {
+  const size_t a = small_workspace_bytes(B, F), b = wide_workspace_bytes(B, F);
+  return a > b ? a : b;
+}
+
+static int fwd_ws(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F, const void* blob, size_t blob_bytes,
+                  float* out, float* latent, uint8_t* valid, void* workspace, size_t ws_bytes, void* stream) {
+  int mode = 0;
+  if (int rc = check_blob_args(B, F, blob, blob_bytes, out, &mode)) return rc;
+  if (B > 0 && !raw && (!x || ldx < F)) return fail(NLML_E_BADARG, "encoder_heads: null x or ldx < F");
+  if (mode == NLML_MODE_BF16) return launch_encoder_heads_bf16(x, ldx, raw, normalize, B, F, blob, out, latent, valid, stream);
+  if (!split_f16(mode)) return launch_encoder_heads_f32(x, ldx, raw, normalize, B, F, blob, out, latent, valid, nullptr, nullptr, stream);
+  const int split = mode == NLML_MODE_F16X2S;
+  if (B <= kSmallMax)
+    return launch_encoder_heads_f16x2_small(x, ldx, raw, normalize, B, F, blob, out, latent, valid, workspace, ws_bytes, split, stream);
+  if (split && B >= kWideMin && wide_supported(raw ? raw : x, raw ? NLML_F_REFERENCE : ldx, F))
+    return launch_encoder_heads_f16x2_wide(x, ldx, raw, normalize, B, F, blob, out, latent, valid, workspace, ws_bytes, stream);
+  return launch_encoder_heads_f16x2(x, ldx, raw, normalize, B, F, blob, out, latent, valid, split, stream);
+}
+
+int nlml_encoder_heads_fwd_ws(const float* x, int64_t ldx, int64_t B, int F, const void* blob, size_t blob_bytes,
+                              float* out, float* latent, uint8_t* valid, void* workspace, size_t ws_bytes, void* stream) {
+  return fwd_ws(x, ldx, nullptr, 0, B, F, blob, blob_bytes, out, latent, valid, workspace, ws_bytes, stream);
+}
+
+int nlml_landmarks_to_pose_ws(const float* raw, int64_t B, int normalize, const void* blob, size_t blob_bytes,
+                              float* out, float* latent, uint8_t* valid, void* workspace, size_t ws_bytes, void* stream) {
+  if (B > 0 && !raw) return fail(NLML_E_BADARG, "landmarks_to_pose: null raw");
+  return fwd_ws(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, blob_bytes, out, latent, valid, workspace, ws_bytes, stream);
+}
+
 // The matrix-core order reads Wm and the x rows with 16-byte vector loads (tucker_common.h load11 / tucker_few)
 static int check_td_fast_alignment(const float* Wm, const float* x, int64_t ldx, const char* who) {
   if ((reinterpret_cast<uintptr_t>(Wm) & 15) || (reinterpret_cast<uintptr_t>(x) & 15) || (ldx & 3)) {
