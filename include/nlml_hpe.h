@@ -157,10 +157,12 @@ int nlml_landmarks_to_pose_small(const float* raw, int64_t B, int normalize,
                                  const void* blob, size_t blob_bytes, float* out, float* latent, uint8_t* valid,
                                  void* workspace, size_t ws_bytes, void* stream);
 
-/* The same forward for LARGE batches in NLML_MODE_F16X2S: the three big layers as one launch each over 128-FACE tiles (eight waves per
- * workgroup, 256 neurons x 128 faces per pass, activations staged through LDS) plus the tail per 64-face tile and the f32 re-evaluation
- * launch -- five launches.  A fused 64-face tile streams the 9.6 MB of weights through its CU once per 64 faces and that stream,
- * not the matrix pipe, sets its time; the 128-face tile shape needs 2/3 of the operand bytes per MFMA (csrc/encoder_heads_f16x2_wide.hip).
+/* The same forward over 128-FACE tiles in NLML_MODE_F16X2S: the three big layers in passes of 256 neurons x 128 faces (eight waves per
+ * workgroup, activations staged through LDS, layer outputs handed over through global memory) plus the tail per 64-face tile and the f32
+ * re-evaluation launch.  A fused 64-face tile streams the 9.6 MB of weights through its CU once per 64 faces; the 128-face tile shape needs
+ * 2/3 of the operand bytes per MFMA (csrc/encoder_heads_f16x2_wide.hip).  MEASURED SLOWER than the fused kernel (0.96 ms against 0.875 ms
+ * per 65,536 faces: what the weights save, the hand-over through memory costs -- DESIGN.md section 3), so nothing picks it by default; it
+ * is kept as a second, independent implementation of the same arithmetic.
  * Bit-identical to nlml_encoder_heads_fwd / nlml_landmarks_to_pose with the same blob.  Input layout: F % 4 == 0, rows 16-byte aligned
  * (ldx % 4 == 0), an even number of 64-column groups in layer 0 (the reference's 1,404 columns qualify) -- else NLML_E_BADARG.
  * `workspace`: nlml_encoder_heads_workspace_bytes(B, F) bytes, 16-byte aligned, contents irrelevant before and after.
@@ -173,8 +175,8 @@ int nlml_landmarks_to_pose_wide(const float* raw, int64_t B, int normalize,
                                 void* workspace, size_t ws_bytes, void* stream);
 
 /* THE FORWARD WITH A WORKSPACE: picks the fastest of the paths above for the batch size and the blob's mode (split-f16 modes: the
- * layer-per-launch path up to 4,096 faces; NLML_MODE_F16X2S from 16,384 faces: the 128-face-tile path where the input layout allows it;
- * the fused kernel otherwise and for the other modes, which ignore the workspace).  Same bits whichever path runs.  This is what the
+ * layer-per-launch path up to 4,096 faces; the fused kernel otherwise and for the other modes, which ignore the workspace; the
+ * 128-face-tile path only when the environment asks for it, NLML_K2_WIDE_MIN=<faces>).  Same bits whichever path runs.  This is what the
  * host layer calls (nlml_hpe_amd/model.py) and what bench.py times.
  * `workspace`: at least nlml_encoder_heads_workspace_bytes(B, F) bytes (>= the _small and _wide paths' needs), 16-byte aligned.
  */

@@ -1,6 +1,7 @@
 // abi.cpp -- the extern "C" surface declared in include/nlml_hpe.h: argument checks, then the
 // launchers in the .hip files.  No allocation, no synchronisation, no global mutable state.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/nlml_hpe.h"
@@ -147,7 +148,13 @@ int nlml_landmarks_to_pose_wide(const float* raw, int64_t B, int normalize, cons
 // ---- the forward with a caller-provided workspace: the fastest path for the batch size and the blob's mode -------------------------
 // (measured crossovers, tools/k2_crossover.py and bench.py extra.k2_batch_sweep)
 static const int64_t kSmallMax = 4096;     // split-f16 modes: up to here the layer-per-launch path over 64-face tiles
-static const int64_t kWideMin = 16384;     // NLML_MODE_F16X2S: from here the 128-face-tile path
+// The 128-face-tile path (encoder_heads_f16x2_wide.hip) is bit-identical to the fused kernel and was built to beat it at large batches; measured
+// (round 5) it does not -- 0.96 ms against 0.875 ms per 65,536 faces -- so the dispatcher never picks it by
+// itself.  NLML_K2_WIDE_MIN=<faces> routes batches from that size on through it (A/B runs; the explicit _wide entry points always do).
+static int64_t wide_min() {
+  static const int64_t v = [] { const char* e = getenv("NLML_K2_WIDE_MIN"); return e && e[0] ? (int64_t)atoll(e) : (int64_t)-1; }();
+  return v;
+}
 
 size_t nlml_encoder_heads_workspace_bytes(int64_t B, int F) {
   const size_t a = small_workspace_bytes(B, F), b = wide_workspace_bytes(B, F);
@@ -164,7 +171,7 @@ static int fwd_ws(const float* x, int64_t ldx, const float* raw, int normalize, 
   const int split = mode == NLML_MODE_F16X2S;
   if (B <= kSmallMax)
     return launch_encoder_heads_f16x2_small(x, ldx, raw, normalize, B, F, blob, out, latent, valid, workspace, ws_bytes, split, stream);
-  if (split && B >= kWideMin && wide_supported(raw ? raw : x, raw ? NLML_F_REFERENCE : ldx, F))
+  if (split && wide_min() >= 0 && B >= wide_min() && wide_supported(raw ? raw : x, raw ? NLML_F_REFERENCE : ldx, F))
     return launch_encoder_heads_f16x2_wide(x, ldx, raw, normalize, B, F, blob, out, latent, valid, workspace, ws_bytes, stream);
   return launch_encoder_heads_f16x2(x, ldx, raw, normalize, B, F, blob, out, latent, valid, split, stream);
 }
