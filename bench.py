@@ -160,7 +160,19 @@ def spawn_ranks(n: int, script: str = None, argv: list = None) -> int:
     return rc
 
 
-K2_KERNEL_MARKS = ("encoder_heads_", "prepass_kernel", "layer_kernel", "tail_kernel")   # the kernels of one K2 step
+# the kernels of one K2 step (every kernel of the library's nlml:: namespace that a forward launches)
+K2_KERNEL_MARKS = ("encoder_heads_", "prepass_kernel", "layer_kernel", "tail_kernel", "tail_encoder_kernel", "head_kernel",
+                   "wide_layers_kernel", "wide_pass_kernel", "tail64_kernel")
+
+
+def expected_k2_launches(mode: str, layered: bool) -> int:
+    """Launches per forward by (mode, path): strict fused = the eight-wave kernel + the f32 re-evaluation launch; strict layered = pre-pass,
+    three layers, tail_encoder_kernel, head_kernel, re-evaluation; opt-in fast mode 1 / 5; f32 and bf16 one fused launch."""
+    if mode == "f16x2s":
+        return 7 if layered else 2
+    if mode == "f16x2":
+        return 5 if layered else 1
+    return 1
 PMC_CHILD_WARM, PMC_CHILD_STEPS = 3, 10
 
 
@@ -210,7 +222,10 @@ def measure_traffic(args):
         n_total = PMC_CHILD_WARM + PMC_CHILD_STEPS
         if len(vals) % n_total:
             return None, f"not measured: {len(vals)} kernel rows in the {counter} pass do not divide into {n_total} steps"
-        per = len(vals) // n_total                          # kernels per step (1 fused, 5 layer-per-launch)
+        per = len(vals) // n_total                          # kernels per step
+        want = expected_k2_launches(args.mode, 0 < args.batch <= 4096 and args.mode in ("f16x2", "f16x2s"))
+        if per != want:
+            return None, f"not measured: {per} kernel rows per step in the {counter} pass, {want} launches expected for mode {args.mode} (a kernel name is missing from K2_KERNEL_MARKS?)"
         timed = vals[PMC_CHILD_WARM * per:]
         per_step[counter] = sum(v for _, v in timed) / PMC_CHILD_STEPS
     b = (2.0 * per_step["FETCH_SIZE"] + per_step["WRITE_SIZE"]) * 1024.0
@@ -367,13 +382,18 @@ def main():
                                   "limit (clock ~1.9 GHz instead of 2.4), see DESIGN.md section 3"}
             dtype = args.mode
             what = ("split-f16 strict-fast mode (two f16 pieces per f32 operand on the f16 matrix cores, f32 accumulate, the small products of each K step "
-                    "in accumulators of their own; the default: inside the reference's own error at the operating range, see cpu_baseline.parity_check_operating_range)")
+                    "in accumulators of their own; the default.  Parity at the operating range (FX3c, 16,384 faces): distance from the f64 truth 0.88x the PINNED "
+                    "reference's (fixture generated in the build container) / 1.14x torch-f32's on the GPU box's host (profiles/r04_parity_soak_1M.json); "
+                    "0.03-0.07 % of the faces differ from the reference's batched output by more than 1e-4 deg (f32 mode: 0.002-0.012 %) -- "
+                    "cpu_baseline.parity_check_operating_range has this run's figures)")
             if args.mode == "f16x2":
                 what = "split-f16 OPT-IN fast mode (single accumulators where registers are short): 1.10x the reference's error at the operating range -- not the parity default"
         else:
             peak, kernel, roof_extra, dtype, what = PEAK_F32_MFMA_TFLOPS, "encoder_heads_f32_kernel", {}, "f32", "f32 strict parity mode (layers 0-3 summed in blocks of 128 k)"
         rec = {
-            "metric": "faces_per_sec", "value": value, "unit": "faces/s", "n_gpus": world,
+            "metric": "faces_per_sec", "value": value,
+            "value_cold": (world * B * args.steps / cold_elapsed) if cold_elapsed is not None else None,   # straight after start-up, W warm-ups only
+            "unit": "faces/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: gloo, shared devices -- not a measurement)",
@@ -389,7 +409,6 @@ def main():
                          "hbm_frac": B * (BYTES_PER_FACE_K2[F]) / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, **roof_extra},
         }
         if cold_elapsed is not None:
-            rec["value_cold"] = world * B * args.steps / cold_elapsed
             rec["warmup_effective"] = args.warmup + args.steps + int(args.settle_ms) + args.warmup
             rec["cold_note"] = (f"`warmup` is the flag as passed; the reported K steps are preceded by warmup_effective = {rec['warmup_effective']} "
                                 f"untimed-or-separately-timed steps: W={args.warmup} warm-ups + K={args.steps} steps timed as value_cold (straight after "
@@ -499,17 +518,26 @@ def parity_operating_range(ops, weights, dev, heads, mode, mode_name, also=()):
         g2 = ops.encoder_heads_fwd(torch.from_numpy(x).to(dev), b2, 1404).cpu().numpy()
         other[name2] = {"kernel_vs_f64_truth": stats(g2, truth), "kernel_vs_reference_batched": stats(g2, g3c["rad"]),
                         "kernel_vs_reference_batch1": stats(g2, g3c["rad_b1"])}
+    vs_batched = stats(got, g3c["rad"])
+    f32_frac = vs_batched["frac_above_1e-4_deg"] if mode_name == "f32" else other.get("f32", {}).get("kernel_vs_reference_batched", {}).get("frac_above_1e-4_deg")
+    k_truth, r_truth = stats(got, truth), stats(g3c["rad"], truth)
     return {"faces": 16384, "mode": mode_name, "pose_span_deg": [float(np.degrees(truth.min())), float(np.degrees(truth.max()))],
-            "kernel_vs_f64_truth": stats(got, truth), "other_modes": other,
-            "reference_batched_vs_f64_truth": stats(g3c["rad"], truth),
+            # the two figures north_star's "within 1e-4 deg of the reference CPU path" turns into at this range, side by side:
+            "frac_above_1e-4_deg_vs_reference_batched": {"timed_kernel": vs_batched["frac_above_1e-4_deg"], "f32_kernel": f32_frac,
+                                                         "reference_batch1_vs_itself_batched": stats(g3c["rad_b1"], g3c["rad"])["frac_above_1e-4_deg"]},
+            "distance_ratio_vs_pinned_reference": {q: k_truth[q] / r_truth[q] for q in ("p50_deg", "p99_deg", "max_deg")},
+            "kernel_vs_f64_truth": k_truth, "other_modes": other,
+            "reference_batched_vs_f64_truth": r_truth,
             "reference_batch1_vs_f64_truth": stats(g3c["rad_b1"], truth),
-            "kernel_vs_reference_batched": stats(got, g3c["rad"]),
+            "kernel_vs_reference_batched": vs_batched,
             "kernel_vs_reference_batch1": stats(got, g3c["rad_b1"]),
             "reference_batch1_vs_reference_batched": stats(g3c["rad_b1"], g3c["rad"]),
             "note": "north_star's bar is 1e-4 deg against the reference's CPU output; at this range the reference's own two call "
                     "shapes differ by up to 1.2e-4 deg, so the statement is statistical: kernel vs truth next to reference vs truth; "
                     "kernel_vs_reference_batch1 is against the call shape the reference's entry points really use (one face per call, "
-                    "NLML_HPE_Test.py:262-272), kernel_vs_reference_batched against one batched call"}
+                    "NLML_HPE_Test.py:262-272), kernel_vs_reference_batched against one batched call.  The reference's own distance depends on its "
+                    "host's BLAS: these are ratios to the PINNED fixture (generated in the build container); against torch-f32 on the GPU box's host the "
+                    "strict-fast mode read 1.14 / 1.12 / 1.10x and the f32 kernel 0.95 / 0.91 / 0.93x on 1,048,576 faces (profiles/r04_parity_soak_1M.json)"}
 
 
 def td_cpu_baseline(weights, synth):
@@ -577,6 +605,24 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     ex["k2_f16x2s_features_F1404"] = k2(lambda: ops.encoder_heads_fwd(feats, blob_hxs, 1404), 1404, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
     blob136_hxs = torch.from_numpy(weights.pack_blob(sd136, heads, _lib.MODE_F16X2S)).to(dev)
     ex["k2_f16x2s_features_F136"] = k2(lambda: ops.encoder_heads_fwd(x136, blob136_hxs, 136), 136, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
+    # Batch-size sweep in the default mode, through the dispatch the host layer uses (HIPPoseModel: layer-per-launch path up to 4,096 faces,
+    # fused kernel above): one forward per launch sequence, HIP events.  A forward is a chain of 11 dependent layers: the layer-per-launch
+    # path costs ~45 us for ANY batch it takes (seven launches), the fused kernel one tile time (~0.15 ms) for any batch up to one round
+    # of tiles (16,384 faces) -- so faces/s climbs with the batch until the chip is full; `frac_of_full` is against the 65,536-face rate.
+    from nlml_hpe_amd.model import HIPPoseModel
+    sweep, full_rate = [], None
+    for Bs in (65536, 32768, 16384, 8192, 5120, 4096, 2000, 512, 64):
+        r = raw[:Bs].contiguous()
+        small = 0 < Bs <= HIPPoseModel.small_batch_max("f16x2s")
+        f = (lambda r=r: ops.landmarks_to_pose_small(r, blob_hxs, True)) if small else (lambda r=r: ops.landmarks_to_pose(r, blob_hxs, True))
+        ms = time_kernel(f, 60 if Bs >= 16384 else 200, warm=30)
+        rate = Bs / ms * 1e3
+        full_rate = rate if full_rate is None else full_rate
+        sweep.append({"faces": Bs, "ms": ms, "faces_per_sec": rate, "frac_of_full": rate / full_rate, "path": "layer-per-launch" if small else "fused"})
+    ex["k2_batch_sweep"] = {"mode": "f16x2s", "entry": "landmarks_to_pose (raw landmarks, normalisation fused)", "points": sweep,
+                            "timing": EV.format(n="60-200", w=30),
+                            "note": "below ~6,800 faces a launch cannot reach 60 % of the full-batch rate: 2,000 faces in 45 us (the seven-launch "
+                                    "floor of the layer-per-launch path) would be 44 M faces/s; see DESIGN.md section 3, small and mid-size batches"}
     # (the blocks the two outputs will most likely be carved from are poisoned first: a launch that wrote nothing would otherwise
     # leave the previous call's pose in its torch.empty output and could show up as a difference of exactly 0)
     poison = [torch.full((B, 3), float("nan"), device=dev) for _ in range(2)]

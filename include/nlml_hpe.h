@@ -91,8 +91,12 @@ int nlml_normalize_ipd(const float* raw, int64_t B, int normalize,
  *       (w_lo*x_hi, w_hi*x_lo) accumulate in registers of their own in layers 0 to 2 and join the big sum once per K
  *       block: the matrix instruction truncates its products to the running sum's exponent, which is what costs
  *       NLML_MODE_F16X2 its distance (profiles/r03_mfma_f16_numerics_probe.txt; that mode has room for the second accumulator set only from
- *       layer 1's second K half on).  Strict parity at matrix-core speed, THE DEFAULT of the host layer: on FX3c
- *       no farther from the exact result than the reference itself, at ~0.9x NLML_MODE_F16X2's faces/s (an eight-wave kernel,
+ *       layer 1's second K half on).  THE DEFAULT of the host layer.  Parity at the operating range (FX3c, 16,384 faces): 1.50e-5 /
+ *       4.65e-5 / 9.2e-5 deg from the exact result = 0.88 / 0.85 / 0.93x the PINNED reference's own distance (fixture generated in the
+ *       build container) but 1.14 / 1.12 / 1.10x torch-f32's on the GPU box's host (1,048,576 faces, profiles/r04_parity_soak_1M.json:
+ *       the reference's distance depends on its host's GEMM blocking); 0.03-0.07 % of the faces differ from the reference's batched
+ *       OUTPUT by more than 1e-4 deg (NLML_MODE_F32: 0.002-0.012 %, what the reference shows against itself): the looser of the two
+ *       parity-class modes -- NLML_MODE_F32 is the one to use where 1e-4 deg must hold face by face.  ~0.9x NLML_MODE_F16X2's faces/s (an eight-wave kernel,
  *       csrc/encoder_heads_f16x2_w8.hip; layer 0 runs in two passes over x to make room for the second accumulator set).
  *       Packed image: NLML_MODE_F16X2's, 256 bytes, then a complete NLML_MODE_F32 image (the size still names the mode).
  *       Range behaviour: a tile with faces beyond f16's range is re-evaluated whole on the f32 matrix cores from the f32 image by a

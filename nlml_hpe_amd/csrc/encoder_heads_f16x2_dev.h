@@ -762,7 +762,9 @@ __device__ __forceinline__ void tail_stages(const Ctx& c, const Args& a, int64_t
     const bool mine = ONEFB ? c.h == 0 : true;
     const unsigned long long m = __ballot(mine && row0 + fl < a.B && *rescue_flag(c.lds, fl) != 0);
     const unsigned long long mask = ONEFB ? (m & 0xffffffffull) << (32 * fbsel) : m;
-    if (mask && __popcll(mask) <= RESCUE_UP_TO) rescue_tile(a.x, a.ldx, a.F, a.norm, a.blob, a.out, a.latent, c.lds, row0, mask);
+    if constexpr (RESCUE_UP_TO > 0) {   // (the strict kernels, RESCUE_UP_TO == 0, carry no slow-path code: their flagged faces go to the f32 re-evaluation launch)
+      if (mask && __popcll(mask) <= RESCUE_UP_TO) rescue_tile(a.x, a.ldx, a.F, a.norm, a.blob, a.out, a.latent, c.lds, row0, mask);
+    }
   }
 #endif
 }

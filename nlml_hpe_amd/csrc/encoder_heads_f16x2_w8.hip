@@ -23,6 +23,13 @@
 #include "encoder_heads_f16x2_dev.h"
 #include "layout.h"
 
+// Waves 4-7 of a workgroup end while waves 0-3 go on through barriers: that is defined by the gfx9 ISA's S_BARRIER (terminated waves
+// are not waited for), not by the HIP programming model -- so this file builds for the targets where the rule was read and tested, and
+// nowhere else (an architecture with split or named barriers would hang instead of failing).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "encoder_heads_f16x2_w8.hip relies on S_BARRIER ignoring terminated waves (gfx942 / gfx950)"
+#endif
+
 namespace nlml {
 namespace hx {
 

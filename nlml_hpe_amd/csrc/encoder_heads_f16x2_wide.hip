@@ -111,6 +111,11 @@ struct Lane {
 // staging has four rows x (h, half) per group (plain lane order: 2-way conflicts).
 __device__ __forceinline__ int swz16(int f, int h, int t) { return ((f ^ (4 * h + t)) + 32 * h) * 16; }
 
+// quads (16 bytes) of one 128-face tile in the two hand-over buffers: bufA holds layer 0's input (4 * k16 quads per face) or layer 1's
+// output (128), bufB layer 0's output (256) or layer 2's (64)
+__host__ __device__ inline size_t tile_quads_A(int k16_e0) { return (size_t)(4 * k16_e0 > 128 ? 4 * k16_e0 : 128) * WFACES; }
+constexpr size_t TILE_QUADS_B = (size_t)256 * WFACES;
+
 // Number of 256-neuron passes and the quad-major geometry of a stage
 template <int STAGE> struct StageGeo {
   static constexpr int NBS = hx::kStages[STAGE].nb;                  // neuron blocks per job
@@ -137,9 +142,12 @@ __device__ __forceinline__ void wide_stage(const WArgs& a, LdsB* lds, const Lane
   const f32x4* blob4 = reinterpret_cast<const f32x4*>(a.blob);
   const float inv = reinterpret_cast<const Header*>(a.blob)->inv_scale[STAGE];   // (read once, before any store; first needed by the first epilogue)
 
-  // quad-major buffers: layer 0 reads x / writes bufA (scratch) and bufB; layer 1 bufB -> bufA; layer 2 bufA -> bufB
-  const f32x4* qin = (STAGE == ST_E1 ? a.bufB : a.bufA) + (size_t)tile * (4 * K16) * WFACES;
-  f32x4* qout = (STAGE == ST_E1 ? a.bufA : a.bufB) + (size_t)tile * G::KQ_OUT * WFACES;
+  // quad-major buffers: layer 0 reads x / writes bufA (scratch) and bufB; layer 1 bufB -> bufA; layer 2 bufA -> bufB.  A tile's region in
+  // a buffer is the same whoever uses it (the largest tenant's size): with a stride per tenant one tile's layer-1 output lay inside another
+  // tile's layer-0 scratch, and workgroups are not in step
+  const size_t strideA = tile_quads_A(a.k16_e0), strideB = TILE_QUADS_B;
+  const f32x4* qin = (STAGE == ST_E1 ? a.bufB + (size_t)tile * strideB : a.bufA + (size_t)tile * strideA);
+  f32x4* qout = (STAGE == ST_E1 ? a.bufA + (size_t)tile * strideA : a.bufB + (size_t)tile * strideB);
 
   // ---- weights: block 8*pass + wv of the stage
   auto wblock = [&](int pass) {
@@ -175,7 +183,7 @@ __device__ __forceinline__ void wide_stage(const WArgs& a, LdsB* lds, const Lane
     live = r < a.B;
     r = live ? r : a.B - 1;
     p = a.x + r * a.ldx;
-    xscr = a.bufA + (size_t)tile * (4 * K16) * WFACES + (size_t)c4 * WFACES + srow;   // + (16 g + 4 i) * WFACES
+    xscr = a.bufA + (size_t)tile * strideA + (size_t)c4 * WFACES + srow;   // + (16 g + 4 i) * WFACES
     if (NORM) {   // exactly K1's arithmetic: the f32 value the reference feeds the network, bit for bit
       const double dx = (double)p[99] - (double)p[789], dy = (double)p[100] - (double)p[790], dz = (double)p[101] - (double)p[791];
       ipd = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
@@ -557,7 +565,7 @@ __global__ __launch_bounds__(256, 1) void tail64_kernel(Args a, const f32x4* __r
   h8 wr3[ring_slots(1, 2)][1][2];
   tail_pre_e3<false>(c, acc3, wr3);                           // E3's bias and first weights fly while the image is filled
   // quad (kq, face) of the 128-face tile (tile >> 1), faces 64 (tile & 1) ..: columns 4 kq .. + 3 of image row `face`, both planes
-  const f32x4* src = qin + (size_t)(tile >> 1) * 64 * hxw::WFACES + 64 * (tile & 1);
+  const f32x4* src = qin + (size_t)(tile >> 1) * hxw::TILE_QUADS_B + 64 * (tile & 1);
   typedef unsigned u2 __attribute__((ext_vector_type(2)));
   for (int i = tid; i < 64 * 64; i += 256) {                  // layer 2's output: 256 columns = 64 quads, 64 faces
     const int face = i & 63, kq = i >> 6;
@@ -583,8 +591,8 @@ bool wide_supported(const float* x, int64_t ldx, int F) {
 }
 
 // per 128-face tile: bufA = max(layer 0's input, layer 1's output) quads, bufB = layer 0's output (layer 2's is smaller)
-static size_t wide_bufA_quads(int F) { const size_t q = (size_t)4 * e0_k16(F); return (q > 128 ? q : 128) * hxw::WFACES; }
-static size_t wide_bufB_quads() { return (size_t)256 * hxw::WFACES; }
+static size_t wide_bufA_quads(int F) { return hxw::tile_quads_A(e0_k16(F)); }
+static size_t wide_bufB_quads() { return hxw::TILE_QUADS_B; }
 
 size_t wide_workspace_bytes(int64_t B, int F) {
   if (B <= 0 || F <= 0) return 0;

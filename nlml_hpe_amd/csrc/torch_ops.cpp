@@ -29,6 +29,11 @@ void need(const at::Tensor& t, const char* name, at::ScalarType dt) {
   TORCH_CHECK(t.scalar_type() == dt, name, ": expected ", dt, ", got ", t.scalar_type());
 }
 
+// a buffer whose data_ptr() / numel() are handed to the C ABI as (pointer, size): it must be one dense run of bytes
+void need_dense(const at::Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_contiguous(), name, ": expected a contiguous tensor (its data_ptr() and numel() go to the kernel as pointer and size)");
+}
+
 void same_device(const at::Tensor& a, const at::Tensor& b, const char* nb) {
   TORCH_CHECK(a.device() == b.device(), nb, " is on ", b.device(), " but the first operand is on ", a.device(),
               ": all operands must share one GPU");
@@ -69,6 +74,7 @@ at::Tensor normalize_ipd(const at::Tensor& raw_, bool normalize) {
 at::Tensor encoder_heads_fwd(const at::Tensor& x_, const at::Tensor& blob, int64_t F) {
   need(x_, "x", at::kFloat);
   need(blob, "packed_w", at::kByte);
+  need_dense(blob, "packed_w");
   same_device(x_, blob, "packed_w");
   TORCH_CHECK(x_.dim() == 2 && x_.size(1) == F, "x: expected [B,", F, "], got ", x_.sizes());
   const at::Tensor x = x_.stride(1) == 1 ? x_ : x_.contiguous();
@@ -83,6 +89,7 @@ at::Tensor encoder_heads_fwd(const at::Tensor& x_, const at::Tensor& blob, int64
 at::Tensor landmarks_to_pose(const at::Tensor& raw_, const at::Tensor& blob, bool normalize) {
   need(raw_, "raw", at::kFloat);
   need(blob, "packed_w", at::kByte);
+  need_dense(blob, "packed_w");
   same_device(raw_, blob, "packed_w");
   TORCH_CHECK(raw_.dim() == 3 && raw_.size(1) == 468 && raw_.size(2) == 3, "raw: expected [B,468,3], got ", raw_.sizes());
   const at::Tensor raw = raw_.contiguous();
@@ -97,7 +104,9 @@ at::Tensor landmarks_to_pose(const at::Tensor& raw_, const at::Tensor& blob, boo
 at::Tensor encoder_heads_fwd_small(const at::Tensor& x_, const at::Tensor& blob, int64_t F, const at::Tensor& ws) {
   need(x_, "x", at::kFloat);
   need(blob, "packed_w", at::kByte);
+  need_dense(blob, "packed_w");
   need(ws, "workspace", at::kByte);
+  need_dense(ws, "workspace");
   same_device(x_, blob, "packed_w");
   same_device(x_, ws, "workspace");
   TORCH_CHECK(x_.dim() == 2 && x_.size(1) == F, "x: expected [B,", F, "], got ", x_.sizes());
@@ -113,7 +122,9 @@ at::Tensor encoder_heads_fwd_small(const at::Tensor& x_, const at::Tensor& blob,
 at::Tensor landmarks_to_pose_small(const at::Tensor& raw_, const at::Tensor& blob, bool normalize, const at::Tensor& ws) {
   need(raw_, "raw", at::kFloat);
   need(blob, "packed_w", at::kByte);
+  need_dense(blob, "packed_w");
   need(ws, "workspace", at::kByte);
+  need_dense(ws, "workspace");
   same_device(raw_, blob, "packed_w");
   same_device(raw_, ws, "workspace");
   TORCH_CHECK(raw_.dim() == 3 && raw_.size(1) == 468 && raw_.size(2) == 3, "raw: expected [B,468,3], got ", raw_.sizes());
@@ -133,6 +144,7 @@ std::tuple<at::Tensor, at::Tensor> landmarks_to_pose_valid(const at::Tensor& raw
                                                            const std::optional<at::Tensor>& ws) {
   need(raw_, "raw", at::kFloat);
   need(blob, "packed_w", at::kByte);
+  need_dense(blob, "packed_w");
   same_device(raw_, blob, "packed_w");
   TORCH_CHECK(raw_.dim() == 3 && raw_.size(1) == 468 && raw_.size(2) == 3, "raw: expected [B,468,3], got ", raw_.sizes());
   const at::Tensor raw = raw_.contiguous();
@@ -141,6 +153,7 @@ std::tuple<at::Tensor, at::Tensor> landmarks_to_pose_valid(const at::Tensor& raw
   OnDevice dev(raw);
   if (ws.has_value()) {
     need(*ws, "workspace", at::kByte);
+    need_dense(*ws, "workspace");
     same_device(raw_, *ws, "workspace");
     check(nlml_landmarks_to_pose_small(raw.data_ptr<float>(), B, normalize ? 1 : 0, blob.data_ptr(), (size_t)blob.numel(),
                                        out.data_ptr<float>(), nullptr, valid.data_ptr<uint8_t>(), ws->data_ptr(), (size_t)ws->numel(),
@@ -252,6 +265,18 @@ at::Tensor pose_metabw(const at::Tensor& x, const at::Tensor&, bool, const at::T
 at::Tensor tucker_objective_meta(const at::Tensor&, const at::Tensor&, const at::Tensor& params, const at::Tensor&, std::string) {
   return at::empty({params.size(0)}, params.options());
 }
+std::tuple<at::Tensor, at::Tensor> pose_valid_meta(const at::Tensor& raw, const at::Tensor&, bool, const std::optional<at::Tensor>&) {
+  return {at::empty({raw.size(0), 3}, raw.options()), at::empty({raw.size(0)}, raw.options().dtype(at::kByte))};
+}
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> tucker_powell_meta(const at::Tensor&, const at::Tensor& x, const at::Tensor&,
+                                                                                           std::string) {
+  const int64_t N = x.size(0);
+  const auto f64 = x.options().dtype(at::kDouble), i32 = x.options().dtype(at::kInt);
+  return {at::empty({N, 8}, f64), at::empty({N}, f64), at::empty({N}, i32), at::empty({N}, i32), at::empty({N}, i32)};
+}
+void video_post_meta(const at::Tensor&, const at::Tensor&, const std::optional<at::Tensor>&, double, double, double, double, double, at::Tensor,
+                     at::Tensor, at::Tensor, at::Tensor, at::Tensor) {}   // everything in place: nothing to shape
+at::Tensor cosine_table_meta(const at::Tensor& angles, const at::Tensor& cosp) { return at::empty({angles.size(0), cosp.size(0)}, cosp.options()); }
 
 }  // namespace
 
@@ -289,4 +314,8 @@ TORCH_LIBRARY_IMPL(nlml_hpe, Meta, m) {
   m.impl("encoder_heads_fwd_small", &pose_meta3w);
   m.impl("landmarks_to_pose_small", &pose_metabw);
   m.impl("tucker_objective", &tucker_objective_meta);
+  m.impl("landmarks_to_pose_valid", &pose_valid_meta);
+  m.impl("tucker_powell", &tucker_powell_meta);
+  m.impl("video_post", &video_post_meta);
+  m.impl("cosine_table", &cosine_table_meta);
 }

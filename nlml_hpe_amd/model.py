@@ -22,9 +22,12 @@ class HIPPoseModel:
         """mode (int constant or name):
           _lib.MODE_F16X2S "f16x2s" (DEFAULT) the strict-fast mode, on the f16 matrix cores: every f32 operand as two f16 pieces,
                                    the small products of each K step in accumulators of their own (layers 0 to 2): at the
-                                   reference's operating range (poses to +-60 deg, FX3c) no farther from the exact result than
-                                   the reference's own f32 forward in p50 / p99 / max; a face whose activations leave f16's
-                                   range is re-evaluated in f32 inside the same launch (no input-range limit);
+                                   reference's operating range (poses to +-60 deg, FX3c) 1.50e-5 / 4.65e-5 / 9.2e-5 deg from the
+                                   exact result = 0.88x the PINNED reference's distance / 1.14x torch-f32's on the GPU box's host;
+                                   0.03-0.07 % of the faces differ from the reference's batched output by more than 1e-4 deg
+                                   (f32 mode: 0.002-0.012 %).  A face whose activations leave f16's range has its tile
+                                   re-evaluated on the f32 matrix cores by a SECOND launch behind the kernel, from the f32 image
+                                   inside the strict blob (which is ~2x the size of the other modes'): no input-range limit;
           _lib.MODE_F16X2 "f16x2"  OPT-IN fast mode, 1.10x THE REFERENCE'S ERROR: the same operands on single accumulators
                                    where registers are short: 1.86e-5 / 5.9e-5 / 1.22e-4 deg from the exact result in
                                    p50 / p99 / max at the operating range = 1.10 / 1.08 / 1.24x the reference's own distance,

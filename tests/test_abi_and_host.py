@@ -94,6 +94,12 @@ def test_launch_entry_points_validate_before_touching_the_gpu():
     assert L.nlml_encoder_heads_fwd(None, 1404, -1, 1404, None, 0, None, None, None, None) == -1
     assert L.nlml_tucker_objective(None, None, 1404, None, None, None, 5, None, None, None) == -1
     assert L.nlml_normalize_ipd(None, 0, 1, None, None, None) == 0          # empty batch is a no-op
+    # the workspace-taking entry points (round 5): sizes on the host, argument checks before any launch
+    assert L.nlml_encoder_heads_workspace_bytes(0, 1404) == 0 and L.nlml_encoder_heads_workspace_bytes(64, 0) == 0
+    assert L.nlml_encoder_heads_workspace_bytes(65536, 1404) >= L.nlml_encoder_heads_small_workspace_bytes(65536, 1404)
+    assert L.nlml_encoder_heads_workspace_bytes(129, 1404) == 2 * (88 * 4 * 128 + 256 * 128) * 16       # two 128-face tiles: input quads + layer-0 output quads
+    assert L.nlml_landmarks_to_pose_ws(None, -1, 1, None, 0, None, None, None, None, 0, None) == -1
+    assert L.nlml_landmarks_to_pose_wide(None, 5, 1, None, 0, None, None, None, None, 0, None) == -1 and b"null" in L.nlml_last_error()
     assert L.nlml_tucker_objective(None, None, 1404, None, None, None, 0, None, None, None) == 0
 
 
@@ -183,6 +189,17 @@ def test_torch_ops_come_from_the_compiled_library():
         torch.ops.nlml_hpe.landmarks_to_pose(torch.zeros(2, 468, 3), torch.zeros(16, dtype=torch.uint8), True)
     m = torch.ops.nlml_hpe.landmarks_to_pose(torch.zeros(7, 468, 3, device="meta"), torch.zeros(16, dtype=torch.uint8, device="meta"), True)
     assert tuple(m.shape) == (7, 3)
+    # every op has a Meta kernel (the video tick's ops had none, so fake-tensor tracing of a tick raised NotImplemented)
+    meta = lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, device="meta")
+    pose, valid = torch.ops.nlml_hpe.landmarks_to_pose_valid(meta(5, 468, 3), meta(16, dtype=torch.uint8), True, None)
+    assert tuple(pose.shape) == (5, 3) and tuple(valid.shape) == (5,) and valid.dtype == torch.uint8
+    res = torch.ops.nlml_hpe.tucker_powell(meta(135, 1404), meta(9, 1404), meta(3, 3, 4, dtype=torch.float64), "reference")
+    assert [tuple(t.shape) for t in res] == [(9, 8), (9,), (9,), (9,), (9,)] and res[2].dtype == torch.int32
+    assert tuple(torch.ops.nlml_hpe.cosine_table(meta(7), meta(3, 4, dtype=torch.float64)).shape) == (7, 3)
+    S = 4
+    torch.ops.nlml_hpe.video_post(meta(S, 3), meta(S, 468, 3), None, 1920.0, 1080.0, 0.4, 100.0, 80.0, meta(S, 6, dtype=torch.float64),
+                                  meta(S, 3, dtype=torch.float64), meta(S, 2, dtype=torch.float64), meta(S, 3, 2, dtype=torch.float64),
+                                  meta(S, dtype=torch.uint8))
 
 
 def test_mode_and_order_names():
