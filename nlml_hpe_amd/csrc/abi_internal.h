@@ -25,7 +25,7 @@ size_t strict_f32_image_offset(int F);
 // to the f32 re-evaluation launch.  0: every face beyond f16's range is re-evaluated on the f32 matrix cores -- one rule, one
 // accuracy class (the strict parity kernel's bits), and no slow-path code inside the strict kernels.
 constexpr int STRICT_INKERNEL_RESCUE_MAX = 0;
-// encoder_heads_bf16.hip (throughput mode)
+// encoder_heads_bf16_w8.hip (throughput mode, eight waves per workgroup)
 int launch_encoder_heads_bf16(const float* x, int64_t ldx, const float* raw, int normalize,
                               int64_t B, int F, const void* blob, float* out, float* latent,
                               uint8_t* valid, void* stream);

@@ -124,7 +124,7 @@ def _bf16_round(a: np.ndarray) -> np.ndarray:
 
 
 def forward_bf16_emulated(x: np.ndarray, p: Params) -> np.ndarray:
-    """Model of the bf16 THROUGHPUT mode (encoder_heads_bf16.hip): weights and every activation that goes
+    """Model of the bf16 THROUGHPUT mode (encoder_heads_bf16_w8.hip): weights and every activation that goes
     through LDS rounded to bf16, products and sums in f64 (the kernel accumulates in f32), bias f32.
     Not a parity oracle for the reference -- it pins the throughput kernel's indexing and rounding points."""
     def lin(h, w, b):

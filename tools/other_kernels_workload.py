@@ -1,6 +1,6 @@
 """The kernels that the K2 bench command does not launch, as profiling workloads:
     rocprofv3 ... -- python3 tools/other_kernels_workload.py <which>
-which = bf16    encoder_heads_bf16_kernel, fused landmarks->pose, 65,536 faces, 30 + 100 launches (BASELINE config 2's named dtype)
+which = bf16    encoder_heads_bf16_w8_kernel, fused landmarks->pose, 65,536 faces, 30 + 100 launches (BASELINE config 2's named dtype)
         small   the five layer-per-launch kernels (prepass, layer x3, tail) at 64 and at 2,000 faces, 30 + 200 steps each, default mode
         video   video_post_kernel behind the 64-face layer-per-launch forward: 64 streams, 300 ticks (BASELINE config 5)
         k1      normalize_ipd_kernel, 65,536 faces, 10 + 100 launches"""
