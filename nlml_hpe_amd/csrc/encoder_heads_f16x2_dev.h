@@ -375,6 +375,7 @@ struct Ctx {
   HdrRegs hdr;
   char* lds;
   int lane, f, h, wv;
+  int helper = 0;   // eight-wave kernel, tail_stages<.., H1W8 = true>: waves 4..7 (wv = wave & 3, helper = 1) stay for the heads' H1 stage
 };
 
 }  // namespace hx
@@ -540,6 +541,24 @@ constexpr int P_G128 = 64 * S_G128 * 2, P_G256 = 64 * S_G256 * 2, P_G64 = 64 * S
 constexpr int O_GA = 0, O_GB = O_GA + 2 * P_G128, O_GC = O_GA, O_GD = O_GB + 2 * P_G256;
 static_assert(O_GD + 2 * P_G64 <= O_LAT, "LDS map (heads, one at a time)");
 
+// H1 of head g by NEURON BLOCK over eight waves: block b (0..7) of the head's eight = job 4g + (b >> 1), block b & 1 of
+// that job, both face blocks -- a weight fragment is still fetched once per tile (no duplicate fetch, unlike the face-block split that was
+// measured slower in round 4), and per accumulator the MFMAs are step_fine's in step_fine's order: the same bits.
+constexpr int H1_WSTEP = 2 * 2 * 64;   // an H1 job streams two blocks x two pieces per K step
+__device__ __forceinline__ void h1_block_pre(const Ctx& c, int g, int b, f32x16 (&acc)[1][2], h8 (&wr)[ring_slots(1, 2)][1][2]) {
+  const int job = 4 * g + (b >> 1), nbh = b & 1;
+  __builtin_amdgcn_sched_barrier(0);
+  load_bias<1, 2>(acc, c.blob4 + c.hdr.b_off(ST_H1) + job * (2 * 8) + nbh * 8, c.h);
+  kloop_pro<1, 2, kStages[ST_H1].k8, H1_WSTEP>(wr, c.blob8 + c.hdr.w_off(ST_H1) + (size_t)job * c.hdr.job_w16(ST_H1) + (nbh * 2) * 64 + c.lane);
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void h1_block_run(const Ctx& c, int g, int b, f32x16 (&acc)[1][2], h8 (&wr)[ring_slots(1, 2)][1][2], int o_ga, int p_ga, int s_ga) {
+  const int job = 4 * g + (b >> 1), nbh = b & 1;
+  const h8* w = c.blob8 + c.hdr.w_off(ST_H1) + (size_t)job * c.hdr.job_w16(ST_H1) + (nbh * 2) * 64 + c.lane;
+  kloop_run<1, 2, kStages[ST_H1].k8, H1_WSTEP>(acc, acc, wr, w, c.lds + o_ga + (c.f * s_ga + 8 * c.h) * 2, p_ga, 32 * s_ga * 2);
+}
+
+template <bool H1W8 = false>
 __device__ __forceinline__ void heads_by_head(const Ctx& c, const Args& a, int64_t row0) {
   const int wv = c.wv;
 #pragma unroll 1
@@ -557,17 +576,30 @@ __device__ __forceinline__ void heads_by_head(const Ctx& c, const Args& a, int64
     job_run<1, 2, ST_H0>(cl, job, acc0, wr0, O_LAT, P_LAT, S_LAT, 16 * g, 0);
     HXS_G0(23);
     HXS_G0(24);
-    job_store<1, 2, ACT_RELU>(cl, acc0, O_GA, P_G128, S_G128, 32 * wv, 0, cl.hdr.inv_scale[ST_H0],
-                              fetch_hook<4, 2, 2, ST_H1>(cl, job, acc1, wr1));
+    f32x16 acc1h[1][2];          // (H1W8: this wave's ONE block of H1_g's eight; waves 4..7 take the other four, tail_helper_w8)
+    h8 wr1h[ring_slots(1, 2)][1][2];
+    if constexpr (H1W8) {
+      h1_block_pre(cl, g, wv, acc1h, wr1h);
+      job_store<1, 2, ACT_RELU>(cl, acc0, O_GA, P_G128, S_G128, 32 * wv, 0, cl.hdr.inv_scale[ST_H0]);
+    } else {
+      job_store<1, 2, ACT_RELU>(cl, acc0, O_GA, P_G128, S_G128, 32 * wv, 0, cl.hdr.inv_scale[ST_H0],
+                                fetch_hook<4, 2, 2, ST_H1>(cl, job, acc1, wr1));
+    }
     HXS_G0(25);
     __syncthreads();
     HXS(13 + 3 * g);
-    // H1_g: 128 -> 256, ReLU; wave = two neuron blocks
+    // H1_g: 128 -> 256, ReLU; wave = two neuron blocks (H1W8: one of eight)
+    if constexpr (H1W8) {
+      h1_block_run(cl, g, wv, acc1h, wr1h, O_GA, P_G128, S_G128);
+      job_store<1, 2, ACT_RELU>(cl, acc1h, O_GB, P_G256, S_G256, 32 * wv, 0, cl.hdr.inv_scale[ST_H1],
+                                fetch_hook<4, 1, 2, ST_H2>(cl, job, acc2, wr2));
+    } else {
     job_run<2, 2, ST_H1>(cl, job, acc1, wr1, O_GA, P_G128, S_G128, 0, 0);
     HXS_G0(26);
     HXS_G0(27);
     job_store<2, 2, ACT_RELU>(cl, acc1, O_GB, P_G256, S_G256, 64 * wv, 0, cl.hdr.inv_scale[ST_H1],
                               fetch_hook<8, 1, 2, ST_H2>(cl, job, acc2, wr2));
+    }
     HXS_G0(28);
     __syncthreads();
     HXS(14 + 3 * g);
@@ -612,9 +644,40 @@ __device__ __forceinline__ void tail_pre_e3(const Ctx& c, f32x16 (&acc)[1][TailE
 // RESCUE_UP_TO: the workgroup re-evaluates its non-finite faces itself (encoder_heads_f16x2_rescue.h: vector ALUs, four faces at a
 // time) when there are at most this many; with more it leaves them non-finite for the f32 re-evaluation launch that follows the
 // strict-fast kernels (encoder_heads.hip, reeval_over).  64 = always here (NLML_MODE_F16X2, which has no f32 image in its blob).
-template <bool ONEFB = false, int RESCUE_UP_TO = 64>
+// The helper waves' side of tail_stages<false, .., H1W8 = true> (eight-wave kernel, waves 4..7): they take blocks 4..7 of every head's H1 and
+// otherwise only keep the workgroup's barrier count -- the SAME sequence of __syncthreads() as the main path below (three in E3..E5, five per
+// head), or the workgroup deadlocks.
+__device__ __forceinline__ void tail_helper_w8(const Ctx& c) {
+  __syncthreads();   // E3 stored
+  __syncthreads();   // E4 stored
+  __syncthreads();   // E5 stored (latent image)
+#pragma unroll 1
+  for (int g = 0; g < 3; ++g) {
+    Ctx cl = c;
+    asm volatile("" : "+v"(cl.lane), "+v"(cl.f), "+v"(cl.h));
+    f32x16 acc1h[1][2];
+    h8 wr1h[ring_slots(1, 2)][1][2];
+    h1_block_pre(cl, g, 4 + cl.wv, acc1h, wr1h);
+    __syncthreads();   // H0_g stored
+    h1_block_run(cl, g, 4 + cl.wv, acc1h, wr1h, O_GA, P_G128, S_G128);
+    job_store<1, 2, ACT_RELU>(cl, acc1h, O_GB, P_G256, S_G256, 32 * (4 + cl.wv), 0, cl.hdr.inv_scale[ST_H1]);
+    __syncthreads();   // H1_g stored
+    __syncthreads();   // H2_g stored
+    __syncthreads();   // H3_g stored
+    __syncthreads();   // H4_g done
+  }
+}
+
+template <bool ONEFB = false, int RESCUE_UP_TO = 64, bool H1W8 = false>
 __device__ __forceinline__ void tail_stages(const Ctx& c, const Args& a, int64_t row0, f32x16 (&acc3)[1][TailE3<ONEFB>::NFB],
                                             h8 (&wr3)[ring_slots(1, TailE3<ONEFB>::NFB)][1][2], int fbsel = 0) {
+  static_assert(!H1W8 || (!ONEFB && RESCUE_UP_TO == 0), "H1 over eight waves: the strict eight-wave kernel's 64-face tail only");
+  if constexpr (H1W8) {
+    if (c.helper) {
+      tail_helper_w8(c);
+      return;
+    }
+  }
   const int wv = c.wv;
   constexpr int NFB3 = TailE3<ONEFB>::NFB;
   const bool do4 = !ONEFB || wv < 2;                      // E4: neuron block wv&1, face block wv>>1 (ONEFB: waves 0,1 on block fbsel)
@@ -659,7 +722,7 @@ __device__ __forceinline__ void tail_stages(const Ctx& c, const Args& a, int64_t
   // ---- heads.  Fused kernel (64 faces in the workgroup): ONE HEAD AT A TIME over both face blocks (heads_by_head below);
   // small-batch tail (ONEFB, 32 faces): the three heads together, the jobs a wave owns in lock step (gloop_run).
   if constexpr (!ONEFB) {
-    heads_by_head(c, a, row0);
+    heads_by_head<H1W8>(c, a, row0);
   } else {
   // ---- heads, one 32-face block at a time; the jobs a wave owns run together (gloop_run)
   const int fb_first = ONEFB ? fbsel : 0, fb_last = ONEFB ? fbsel : 1;

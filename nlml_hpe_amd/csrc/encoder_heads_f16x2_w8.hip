@@ -13,9 +13,11 @@
 //   * two waves per SIMD hide each other's dependent chains: the x staging (f64 normalisation, hi/lo split, LDS writes) and the
 //     epilogues of one wave run under the other's MFMAs without hand-placing every link.
 // The tail (E3, E4, E5, the three heads; 10 % of the FLOPs, stream-bound short stages) is the four-wave code of
-// encoder_heads_f16x2_dev.h run by waves 0-3: waves 4-7 END after layer 2's store.  S_BARRIER waits only for the waves of the
-// workgroup that have not terminated (CDNA ISA, S_BARRIER: "If some waves in the threadgroup have already terminated, this waits on
-// only the surviving waves"), so the tail's barriers keep working among the four survivors.
+// encoder_heads_f16x2_dev.h run by waves 0-3.  Round 4 let waves 4-7 END after layer 2's store (S_BARRIER waits only for the waves of
+// the workgroup that have not terminated: gfx9 ISA, not the HIP programming model); since round 5 they STAY and take blocks 4..7 of every
+// head's H1 stage (tail_helper_w8: the same number of barriers as the main path), so nothing relies on that rule any more.  The gain is
+// small -- 0.918 against 0.921 ms per 65,536 faces, same box, five alternating runs: H1 is bound by its weight stream, not by its
+// MFMAs -- and the bits are unchanged (-DW8_TAIL_EXIT builds round 4's form for A/B).
 #include <hip/hip_runtime.h>
 
 #include "../../include/nlml_hpe.h"
@@ -23,11 +25,11 @@
 #include "encoder_heads_f16x2_dev.h"
 #include "layout.h"
 
-// Waves 4-7 of a workgroup end while waves 0-3 go on through barriers: that is defined by the gfx9 ISA's S_BARRIER (terminated waves
-// are not waited for), not by the HIP programming model -- so this file builds for the targets where the rule was read and tested, and
-// nowhere else (an architecture with split or named barriers would hang instead of failing).
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
-#error "encoder_heads_f16x2_w8.hip relies on S_BARRIER ignoring terminated waves (gfx942 / gfx950)"
+// -DW8_TAIL_EXIT (round 4's form, A/B only): waves 4-7 of a workgroup end while waves 0-3 go on through barriers.  That is defined by
+// the gfx9 ISA's S_BARRIER (terminated waves are not waited for), not by the HIP programming model -- so that form builds for the
+// targets where the rule was read and tested, and nowhere else (an architecture with split or named barriers would hang instead of failing).
+#if defined(W8_TAIL_EXIT) && defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "-DW8_TAIL_EXIT relies on S_BARRIER ignoring terminated waves (gfx942 / gfx950)"
 #endif
 
 namespace nlml {
@@ -374,15 +376,21 @@ __global__ __launch_bounds__(512) void encoder_heads_f16x2_w8_kernel(Args a) {
   __syncthreads();
   W8S(11);
   W8S_WALL(15);
-  if (c.wv >= 4) return;   // waves 4-7 end here; the tail's barriers wait only for the surviving waves (see the header)
+#ifdef W8_TAIL_EXIT   // round 4's form (A/B): waves 4-7 end here; the tail's barriers wait only for the surviving waves (see the header)
+  if (c.wv >= 4) return;
+  constexpr bool H1W8 = false;
+#else                  // round 5: waves 4-7 stay for the heads' H1 stage (blocks 4..7 of each head's eight), tail_helper_w8
+  ct.helper = c.wv >= 4 ? 1 : 0;
+  constexpr bool H1W8 = true;
+#endif
   // (Measured and dropped: on their way out these waves TOUCHED the input rows of the tile that starts one tile time later -- one dword
   // per line, so that its pass 0 finds x in the Infinity Cache instead of HBM: 0.852 ms against 0.834 without, same box.)
 #ifdef HX_STAMPS
   Args at = a;             // the tail's stamps (32 slots per wave, 4 waves per tile) behind the trunk's
   if (a.latent) at.latent = a.latent + (size_t)gridDim.x * 8 * 16 * 2;
-  tail_stages<false, STRICT_INKERNEL_RESCUE_MAX>(ct, at, row0, acc3, wr3);
+  tail_stages<false, STRICT_INKERNEL_RESCUE_MAX, H1W8>(ct, at, row0, acc3, wr3);
 #else
-  tail_stages<false, STRICT_INKERNEL_RESCUE_MAX>(ct, a, row0, acc3, wr3);
+  tail_stages<false, STRICT_INKERNEL_RESCUE_MAX, H1W8>(ct, a, row0, acc3, wr3);
 #endif
 }
 
