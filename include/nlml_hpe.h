@@ -180,8 +180,9 @@ int nlml_landmarks_to_pose_wide(const float* raw, int64_t B, int normalize,
 
 /* THE FORWARD WITH A WORKSPACE: picks the fastest of the paths above for the batch size and the blob's mode (split-f16 modes: the
  * layer-per-launch path up to 4,096 faces; the fused kernel otherwise and for the other modes, which ignore the workspace; the
- * 128-face-tile path only when the environment asks for it, NLML_K2_WIDE_MIN=<faces>).  Same bits whichever path runs.  This is what the
- * host layer calls (nlml_hpe_amd/model.py) and what bench.py times.
+ * 128-face-tile path only when the environment asks for it, NLML_K2_WIDE_MIN=<faces>).  Same bits whichever path runs.  For hosts that
+ * want one call for every batch size; the packaged host layer makes the same choice in Python (nlml_hpe_amd/model.py, `small_batch_max`)
+ * and calls the plain / _small forms, which is also what bench.py times.
  * `workspace`: at least nlml_encoder_heads_workspace_bytes(B, F) bytes (>= the _small and _wide paths' needs), 16-byte aligned.
  */
 size_t nlml_encoder_heads_workspace_bytes(int64_t B, int F);
