@@ -377,14 +377,14 @@ def main():
                           "where its tile has no face beyond f16's range); kernel_ms covers both launches")
             # the stream that bounds the fused split-f16 kernels in fact: every 64-face tile pulls the whole split-f16 weight
             # image (header to tail pad: 9.6 MB at F = 1404) from L2 into its CU once
-            wbytes = float(_lib.lib().nlml_encoder_heads_packed_bytes(F, mode))
+            wbytes = float(_lib.lib().nlml_encoder_heads_packed_bytes(F, _lib.MODE_F16X2))   # the split-f16 image alone (the strict blob also carries the f32 image the re-evaluation launch reads)
             l2_stream = None if layered else {
                 "bytes_per_launch": wbytes * ((B + 63) // 64), "achieved_TBps": wbytes * ((B + 63) // 64) / (kern_ms * 1e-3) / 1e12,
                 "peak_TBps": 34.5, "frac_of_l2_peak": wbytes * ((B + 63) // 64) / (kern_ms * 1e-3) / 1e12 / 34.5,
                 "per_cu_bytes_per_clk_at_1p76GHz": wbytes * ((B + 63) // 64) / (kern_ms * 1e-3) / 256 / 1.76e9,
                 "note": "weights only (x and the hand-overs inside LDS are not in it); peak = MI355X_MICROARCH.md's aggregate L2 rate; a CU of this kernel takes in "
                         "31-35 B/clk from L2 under MFMA + LDS load (stamps, DESIGN.md A.2), 46-51 in a bare stream (profiles/r03_l1_stream_probe.txt): the tile's "
-                        "9.6 MB at 33 B/clk are 290 k of its ~330 k cycles"}
+                        "9.6 MB at 33 B/clk are 290 k of its ~330 k cycles (the figure here is the mean over the whole launch, tail and barriers included)"}
             roof_extra = {"l2_to_cu_weight_stream": l2_stream, "executed_flop_per_launch": SPLIT_PRODUCTS * B * FLOP_PER_FACE[F],
                           "executed_frac": SPLIT_PRODUCTS * achieved / peak,
                           "note": "each algorithmic product runs as 3 f16 MFMA products (hi*hi + hi*lo + lo*hi, f32 accumulate); "
