@@ -83,7 +83,10 @@ __device__ __forceinline__ void step8(f32x16 (&acc)[NB][NFB], const bf16x8 (&wc)
 // `in`: this lane's (face row of block 0, k = 8h).
 template <int NB, int NFB, int K16, int WSTEP>
 __device__ __forceinline__ void kloop8(f32x16 (&acc)[NB][NFB], const bf16x8* __restrict__ w, const __bf16* in, int fb_stride) {
-  constexpr int R = 4, D = R - 1;
+#ifndef BF8_KD
+#define BF8_KD 3
+#endif
+  constexpr int R = 4, D = BF8_KD;
   static_assert(K16 % R == 0, "K steps in whole ring rounds");
   bf16x8 wr[R][NB], xr[2][NFB];
 #pragma unroll

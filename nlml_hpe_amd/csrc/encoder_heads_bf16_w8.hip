@@ -55,26 +55,50 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const Args& a, int64_t ro
   }
   unsigned nzbits = 0u;
 
+  // ONE L2 request per 128-byte line of x (the strict-fast kernel's scheme, encoder_heads_f16x2_w8.hip): a row is 16-byte but not
+  // 128-byte aligned, so the 256 bytes it contributes to a slab touch three lines and the one shared with the next slab used to be
+  // requested twice, a slab apart.  The 16-byte units that lie in a slab's FIRST line (`adv[i]`) are loaded one slab ahead -- one load
+  // instruction then asks for whole lines only -- and wait one slab in `carry`.  Same values into the same LDS bytes.
+#ifdef BF8_NO_XLINE
+  const bool adv[2] = {false, false};
+#else
+  const int xphase = (int)((reinterpret_cast<uintptr_t>(p) >> 4) & 7);   // the row's first 16-byte unit within its line
+  const bool adv[2] = {VEC4 && xphase != 0 && xphase + 2 * (tid & 7) < 8, VEC4 && xphase != 0 && xphase + 2 * (tid & 7) + 1 < 8};
+#endif
   f32x4 set[2];   // ONE staging register set (8 floats per thread), refilled as soon as it has been written to LDS
-  auto gload = [&](int s) {
-    s = s < nslab ? s : nslab - 1;
+  f32x4 carry[2];
+  auto gload_at = [&](int s0, f32x4 (&dst)[2], bool ahead) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      int s = s0 + ((ahead && adv[i]) ? 1 : 0);
+      s = s < nslab ? s : nslab - 1;
       const int k = s * XS_COLS + scol + 4 * i;
       if (VEC4) {
         const int kc = k < F ? k : (NORM ? k - 12 * ((k - F + 15) / 12) : F - 4);   // phase-preserving clamp (zero weights there)
-        set[i] = *reinterpret_cast<const f32x4*>(p + kc);
+        dst[i] = *reinterpret_cast<const f32x4*>(p + kc);
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) set[i][e] = p[k + e < F ? k + e : F - 1];
+        for (int e = 0; e < 4; ++e) dst[i][e] = p[k + e < F ? k + e : F - 1];
       }
     }
   };
+  auto gload = [&](int s) { gload_at(s, set, true); };
   // the staging of a slab in pieces (one per MFMA slot): 0..7 normalise element q, 8 convert + store
   auto lpiece = [&](int piece, int buf_off, bool real_slab) {
     if (piece == 0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(set[i]));
+#ifndef BF8_NO_XLINE
+      if (VEC4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {   // a unit that is loaded a slab ahead stages what it loaded a slab ago
+          const f32x4 t = set[i];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) set[i][e] = adv[i] ? carry[i][e] : t[e];
+          carry[i] = t;
+        }
+      }
+#endif
     }
     if (piece < 8) {
       if (NORM) {
@@ -108,11 +132,17 @@ __device__ __forceinline__ void stage_e0(const Ctx& c, const Args& a, int64_t ro
 
   const int job = jw;
   const bf16x8* w = c.blob8 + c.hdr->w_off[ST_E0] + (size_t)job * c.hdr->job_w16[ST_E0] + (size_t)(4 * nbh) * 64 + c.lane;
-  constexpr int R0 = 4, D0 = R0 - 1;   // weight ring: K step ks in slot ks % 4; a slab holds 4 steps
+#ifndef BF8_D0
+#define BF8_D0 3
+#endif
+  constexpr int R0 = 4, D0 = BF8_D0;   // weight ring: K step ks in slot ks % 4 (a slab holds 4 steps), loaded D0 steps ahead
   static_assert(XS_STEPS == R0, "slab steps == ring slots");
   bf16x8 wr[R0][NB];
   // prologue: slabs 0 and 1 in LDS, slab 2 in the registers; the ring and the bias are requested LAST (so that at the loop's entry no
   // load is younger than the loop's own steady state: hipcc merges the two entries' pending-load states conservatively)
+#ifndef BF8_NO_XLINE
+  if (VEC4) gload_at(0, carry, false);   // slab 0 for the units that run a slab ahead
+#endif
   gload(0);
   lwrite(0, true);
   gload(1);

@@ -146,13 +146,21 @@ __device__ __forceinline__ void step_fine(f32x16 (&acc)[NB][NFB], f32x16 (&accS)
 // issued before the PREVIOUS stage's store and barrier -- the short stages of the tail otherwise expose one L2 latency and the
 // issue time of ~40 loads each -- while the LDS reads and the MFMAs (kloop_run) wait for the barrier.
 constexpr int ring_slots(int nb, int nfb) { return (nb * nfb >= 4) ? 4 : 6; }
+// K steps a ring runs ahead of the MFMAs (at most slots - 1).  -DHX_KLOOP_D4=<n> / -DHX_KLOOP_D6=<n>: experiments with a shallower look-ahead.
+#ifndef HX_KLOOP_D4
+#define HX_KLOOP_D4 3
+#endif
+#ifndef HX_KLOOP_D6
+#define HX_KLOOP_D6 5
+#endif
+constexpr int ring_ahead(int slots) { return slots == 4 ? HX_KLOOP_D4 : HX_KLOOP_D6; }
 
 // WSTEP: fragments (16-byte units per lane, i.e. h8 elements / 64 lanes) between consecutive K steps of the stream `w` points into.
 // The default is a job's own stream (NB blocks x 2 pieces); a wave that takes only NB of a job's blocks (the eight-wave kernel:
 // two of four, one of two) passes the job's full stride and a `w` that points at its first block.
 template <int NB, int NFB, int K16, int WSTEP = NB * 2 * 64>
 __device__ __forceinline__ void kloop_pro(h8 (&wr)[ring_slots(NB, NFB)][NB][2], const h8* __restrict__ w) {
-  constexpr int R = ring_slots(NB, NFB), D = R - 1;
+  constexpr int R = ring_slots(NB, NFB), D = ring_ahead(R);
 #pragma unroll
   for (int d = 0; d < D; ++d) {
     if (d < K16) {
@@ -167,7 +175,7 @@ __device__ __forceinline__ void kloop_pro(h8 (&wr)[ring_slots(NB, NFB)][NB][2], 
 template <int NB, int NFB, int K16, int WSTEP = NB * 2 * 64>
 __device__ __forceinline__ void kloop_run(f32x16 (&acc)[NB][NFB], f32x16 (&accS)[NB][NFB], h8 (&wr)[ring_slots(NB, NFB)][NB][2],
                                           const h8* __restrict__ w, const char* in, int plane, int fb_stride) {
-  constexpr int R = ring_slots(NB, NFB), D = R - 1;
+  constexpr int R = ring_slots(NB, NFB), D = ring_ahead(R);
   h8 xr[2][NFB][2];
 #pragma unroll
   for (int fb = 0; fb < NFB; ++fb)

@@ -49,7 +49,8 @@ __device__ __forceinline__ double div_ipd_w8(double n, double d, double y) {   /
 // +0.6 % faces/s on one box).
 template <typename XHi, typename XLo, typename Extra>
 __device__ __forceinline__ void step_w8(f32x16 (&acc)[2][2], f32x16 (&accS)[2][2], const h8 (&wcur)[2][2], const h8 (&xh)[2], h8 (&xl)[2],
-                                        h8 (&wnext)[2][2], const h8* __restrict__ wp, XHi xload_hi, XLo xload_lo, Extra extra) {
+                                        h8 (&wnext_hi)[2][2], const h8* __restrict__ wp_hi, h8 (&wnext_lo)[2][2], const h8* __restrict__ wp_lo,
+                                        XHi xload_hi, XLo xload_lo, Extra extra) {
 #pragma unroll
   for (int m = 0; m < 12; ++m) {
     const int t = m / 4, nb = (m % 4) / 2, fb = m % 2;
@@ -59,12 +60,12 @@ __device__ __forceinline__ void step_w8(f32x16 (&acc)[2][2], f32x16 (&accS)[2][2
     __builtin_amdgcn_sched_barrier(0);
     if (m == 0) xload_hi(0);
     if (m == 1) xload_hi(1);
-    if (m == 2) wnext[0][0] = wp[0];
-    if (m == 4) wnext[0][1] = wp[64];
-    if (m == 6) wnext[1][0] = wp[128];
+    if (m == 2) wnext_hi[0][0] = wp_hi[0];          // (the hi and the lo pieces may run a different number of steps ahead)
+    if (m == 4) wnext_lo[0][1] = wp_lo[64];
+    if (m == 6) wnext_hi[1][0] = wp_hi[128];
     if (m == 8) xload_lo(0);          // (xl's last reader was MFMA 7)
     if (m == 9) xload_lo(1);
-    if (m == 10) wnext[1][1] = wp[192];
+    if (m == 10) wnext_lo[1][1] = wp_lo[192];
     extra(m);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -100,8 +101,25 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
   }
   unsigned nzbits = 0u;
 
+  // ONE L2 request per 128-byte line of x -- built, bit-identical, measured SLOWER here, kept behind -DW8_XLINE.  A row is 16-byte but not
+  // 128-byte aligned (1,404 floats = 43.9 lines), so the 128 bytes a row contributes to a slab straddle two lines, and the line between
+  // slabs q and q+1 is requested twice, a slab apart (by then the weight stream -- 64 KB per slab -- has pushed it out of the 32-KB L1):
+  // 88 requests per row and pass for 45 lines, 6 % of all the kernel's L2 requests (profiles/r05l1_summary.md).  With -DW8_XLINE the
+  // threads whose 16 bytes lie in a slab's FIRST line (`adv`) load one slab ahead: one load instruction then asks, per row, for exactly
+  // one whole line, and an `adv` thread's value waits one slab in `carry`.  Same values into the same LDS bytes.  Measured on one box,
+  // alternating: 0.880 against 0.844 ms with the weight ring three steps ahead (the four carry registers push the spills from 30 to 52),
+  // 0.834 against 0.826 ms with the ring two steps ahead (21 against 15 spills): the saved requests do not pay for the registers.  The
+  // bf16 kernel, which has the registers, keeps the scheme (+0.8 %).
+#ifndef W8_XLINE
+  const bool adv = false;
+#else
+  const int xphase = (int)((reinterpret_cast<uintptr_t>(p) >> 4) & 7);   // the row's first 16-byte unit within its line
+  const bool adv = VEC4 && xphase != 0 && xphase + (tid & 7) < 8;
+#endif
+
   struct Set { float v[4]; };
-  auto gload = [&](int s, Set& st) {   // columns scol .. scol+3 of slab s
+  [[maybe_unused]] Set carry;
+  auto gload_at = [&](int s, Set& st) {   // columns scol .. scol+3 of slab s
     s = s < nslab ? s : nslab - 1;
 #ifdef W8_ABL_XHOT   // timing-only ablation (wrong results): every slab's x comes from the row's first 128 bytes (L1 / L2 hot)
     s = 0;
@@ -109,7 +127,11 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
     const int k = s * XS_COLS + scol;
     if (VEC4) {
       const int kc = k < F ? k : (NORM ? k - 12 * ((k - F + 15) / 12) : F - 4);   // phase-preserving clamp (zero weights there)
+#ifdef W8_X_NT   // x lines are used once per pass: ask L2 not to keep them in the weights' way (experiment)
+      const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + kc));
+#else
       const f32x4 t = *reinterpret_cast<const f32x4*>(p + kc);
+#endif
 #pragma unroll
       for (int e = 0; e < 4; ++e) st.v[e] = t[e];
     } else {
@@ -117,9 +139,20 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
       for (int e = 0; e < 4; ++e) st.v[e] = p[k + e < F ? k + e : F - 1];
     }
   };
+  auto gload = [&](int s, Set& st) { gload_at(s + (adv ? 1 : 0), st); };   // (slab s+1 in the threads that run a slab ahead)
   auto lw_begin = [&](Set& st) {   // the set's loads must have landed: everything below consumes them
 #pragma unroll
     for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(st.v[e]));
+#ifdef W8_XLINE
+    if (VEC4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {   // a thread that loads a slab ahead stages what it loaded a slab ago
+        const float t = st.v[e];
+        st.v[e] = adv ? carry.v[e] : t;
+        carry.v[e] = t;
+      }
+    }
+#endif
   };
   auto lw_norm = [&](Set& st, int q) {   // element q (static): the plain chain (prologue)
     const int t = q % 3;
@@ -183,8 +216,18 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
   // ahead) fit the register budget since step_w8 single-buffers the lo operands, but need the loop unrolled by two for static set
   // indices, and hipcc's allocation of that 96-MFMA body spills 166 registers, 30 reloads inside the loop: 1.25 ms against 0.84 (measured).
   Set set[2];
-  constexpr int R0 = 4, D0 = R0 - 1;   // weight ring: K step ks in slot ks % 4 = its step within the iteration
+#ifndef W8_D0_HI
+#define W8_D0_HI 2
+#endif
+#ifndef W8_D0_LO
+#define W8_D0_LO 2
+#endif
+  // weight ring: K step ks in slot ks % 4 = its step within the iteration, its hi / lo pieces requested DH / DL steps ahead
+  constexpr int R0 = 4, DH = W8_D0_HI, DL = W8_D0_LO;
   h8 wr[R0][NB][2];
+#ifdef W8_XLINE
+  if (VEC4) gload_at(0, carry);   // slab 0 for the threads that run a slab ahead (their first regular load is slab 1's)
+#endif
   gload(0, set[0]);
   gload(1, set[1]);
   lwrite(0, set[0], true);
@@ -192,11 +235,12 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
   gload(2, set[0]);
   gload(3, set[1]);
 #pragma unroll
-  for (int d = 0; d < D0; ++d)
+  for (int d = 0; d < (DH > DL ? DH : DL); ++d)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int pp = 0; pp < 2; ++pp) wr[d][nb][pp] = wfrag(d)[(nb * 2 + pp) * 64];
+      for (int pp = 0; pp < 2; ++pp)
+        if (d < (pp ? DL : DH)) wr[d][nb][pp] = wfrag(d)[(nb * 2 + pp) * 64];
   __syncthreads();
 
   // reader: lane (f, h) of face block fb reads row 32*fb + f, logical chunk 2*(step & 1) + h of slab (step >> 1): two lane
@@ -231,7 +275,7 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
 #ifndef W8_ABL_NOBAR
       if (t == 3) __syncthreads();
 #endif
-      step_w8(acc, accS, wr[t], xh[t & 1], xl, wr[(t + D0) % R0], wfrag(ks + D0),
+      step_w8(acc, accS, wr[t], xh[t & 1], xl, wr[(t + DH) % R0], wfrag(ks + DH), wr[(t + DL) % R0], wfrag(ks + DL),
               [&](int fb) { xh[(t + 1) & 1][fb] = t < 3 ? xread(xc[(t + 1) & 1], t + 1, fb, 0) : xread(xn, 0, fb, 0); },
               [&](int fb) { xl[fb] = t < 3 ? xread(xc[(t + 1) & 1], t + 1, fb, 1) : xread(xn, 0, fb, 1); },
               [&](int m) {   // the staging of slab s+2 (step 0) and s+3 (step 1), one piece behind an MFMA

@@ -3,6 +3,7 @@
 # The vector-L1 (TCP) / texture-path / L2 (TCC) counters of a workload, one `rocprofv3 --pmc` pass per group (never together with a trace),
 # preceded by `rocprofv3 --list-avail` so that a name this build of the profiler does not know shows up in the log instead of as an empty pass.
 # Output: gpurun_out/pmcl1_<tag>/ + a table on stdout (mean per launch by kernel).
+# (No TA_* / TD_* group: with those rocprofv3 aborted after the workload and sat until its timeout, twice -- round 5.)
 set -u
 TAG=$1; shift
 ROOT=$(pwd)
@@ -16,8 +17,6 @@ GROUPS_=(
   "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE"
   "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_GATE_EN2_sum"
   "TCP_TA_TCP_STATE_READ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TOTAL_ACCESSES_sum TCP_GATE_EN1_sum"
-  "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUFFER_LOAD_WAVEFRONTS_sum"
-  "TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum TA_FLAT_LOAD_WAVEFRONTS_sum"
   "TCC_REQ_sum TCC_READ_sum TCC_BUSY_sum TCC_TAG_STALL_sum"
   "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"
   "SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"
