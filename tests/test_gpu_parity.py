@@ -518,6 +518,25 @@ def test_bf16_fused_landmarks(head_sds, device):
     assert np.degrees(np.abs(fused.cpu().numpy() - ref).max()) <= 0.5
 
 
+@pytest.mark.parametrize("mode_name", ["bf16", "f16x2s", "f16x2", "f32"])
+def test_result_does_not_depend_on_where_a_row_starts_in_its_cache_line(mode_name, head_sds, device):
+    """The kernels stage x in 16-byte units and (bf16: always; strict-fast: with -DW8_XLINE) let the units of a slab's first 128-byte line
+    be loaded one slab ahead, by the row's phase within its line.  Same features behind every phase (base offsets of 0 / 16 / 48 / 112
+    bytes in line-aligned rows, and the packed 5,616-byte rows whose phase changes from row to row) must give the same bits."""
+    from nlml_hpe_amd import _lib
+    sd = synth.encoder_state_dict(1404, seed=0)
+    blob = torch.from_numpy(weights.pack_blob(sd, head_sds, _lib.mode_from_name(mode_name))).to(device)
+    B = 333
+    feats = torch.from_numpy(synth.features(B, 1404, seed=31)).to(device)
+    want, want_lat = ops.encoder_heads_fwd(feats, blob, 1404, return_latent=True)
+    for off in (0, 4, 12, 28):
+        buf = torch.zeros((B, 1408 + 32), dtype=torch.float32, device=device)   # 5,760-byte rows: 45 whole lines
+        view = buf[:, off:off + 1404]
+        view.copy_(feats)
+        got, got_lat = ops.encoder_heads_fwd(view, blob, 1404, return_latent=True)
+        assert torch.equal(got, want) and torch.equal(got_lat, want_lat), (mode_name, off)
+
+
 def test_host_pipeline_overlapped_copies(head_sds, device):
     """Host-resident landmarks through the double-buffered copy/compute pipeline == the direct device call."""
     from nlml_hpe_amd.model import HIPPoseModel
