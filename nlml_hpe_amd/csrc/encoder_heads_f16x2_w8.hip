@@ -259,6 +259,26 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
     xh[0][fb] = xread(xb0, 0, fb, 0);
     xl[fb] = xread(xb0, 0, fb, 1);
   }
+#ifdef W8_XTOUCH
+  // EXPERIMENT (-DW8_XTOUCH; bit-identical, measured 2.8 % SLOWER: 0.890 against 0.866 ms on one box): x lines pulled into L2 through the
+  // SCALAR cache, two iterations before the vector loads ask for them.  Why it loses: scalar loads count in lgkmcnt with the LDS reads, so
+  // every `s_waitcnt lgkmcnt(k)` for an x operand of the next MFMAs also waits until all but k of the 16 touches -- each 300-500 cycles
+  // away -- have come back.  The idea as it was:  A vector load of
+  // a line that is still in HBM (pass A) or the Infinity Cache (pass B) sits 300-500 cycles at the head of the L1's in-order return queue
+  // with every younger weight line behind it (-DW8_ABL_XHOT: 23 k cycles per tile); a touch through the vector path costs the same.
+  // s_load_dword goes CU -> scalar cache -> L2 on a path of its own.  One touch per row and slab: the slab's last dword, i.e. the line
+  // it shares with the next slab.  The destination register is never read; it is kept live (`+s`) across the iteration's barrier, whose
+  // lgkmcnt(0) all touches have passed before the next ones are issued.
+  unsigned xt_sink = 0;
+  auto xtouch = [&](int k, int slab0) {   // touch k of 16: row k & 7 of this wave's eight rows, slab slab0 + (k >> 3)
+    int64_t rr = row0 + 8 * c.wv + (k & 7);
+    rr = rr < a.B ? rr : a.B - 1;
+    int col = (slab0 + (k >> 3)) * XS_COLS + XS_COLS - 1;
+    col = col < F ? col : F - 1;
+    const float* q = a.x + rr * a.ldx + col;
+    asm volatile("s_load_dword %0, %1, 0x0" : "+s"(xt_sink) : "s"(q) : "memory");
+  };
+#endif
   int cur = 0, nxt = XW_BUF;   // byte offsets of the buffer being read / written
   for (int it = 0; it < niter; ++it) {
     const int s = 2 * it;
@@ -275,12 +295,21 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
 #ifndef W8_ABL_NOBAR
       if (t == 3) __syncthreads();
 #endif
+#ifdef W8_XTOUCH
+      if (t == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(xt_sink));   // (free behind the barrier: the last iteration's touches have landed)
+#endif
       step_w8(acc, accS, wr[t], xh[t & 1], xl, wr[(t + DH) % R0], wfrag(ks + DH), wr[(t + DL) % R0], wfrag(ks + DL),
               [&](int fb) { xh[(t + 1) & 1][fb] = t < 3 ? xread(xc[(t + 1) & 1], t + 1, fb, 0) : xread(xn, 0, fb, 0); },
               [&](int fb) { xl[fb] = t < 3 ? xread(xc[(t + 1) & 1], t + 1, fb, 1) : xread(xn, 0, fb, 1); },
               [&](int m) {   // the staging of slab s+2 (step 0) and s+3 (step 1), one piece behind an MFMA
 #ifdef W8_ABL_NOSTAGE
                 return;      // timing-only ablation (wrong results)
+#endif
+#ifdef W8_XTOUCH
+                if (t == 3) {   // slabs s+6 and s+7: their vector loads are issued in the next iteration
+                  if (m < 4) { xtouch(2 * m, s + 6); xtouch(2 * m + 1, s + 6); }
+                  else xtouch(4 + m, s + 6);
+                }
 #endif
                 if (t >= 2) return;
                 Set& st = set[t & 1];
@@ -298,6 +327,9 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
     }
     const int t0 = cur; cur = nxt; nxt = t0;
   }
+#ifdef W8_XTOUCH
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(xt_sink));
+#endif
   if (pass == 0 && a.valid) {  // all-zero feature row == "no face" (FeatureExtractor.py:105-106); 8 lanes share a row
     const unsigned long long m = __ballot(nzbits != 0u);
     if ((tid & 7) == 0 && live) a.valid[row0 + srow] = ((m >> (c.lane & 56)) & 0xFFull) ? 1 : 0;
