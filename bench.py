@@ -382,9 +382,10 @@ def main():
                 "bytes_per_launch": wbytes * ((B + 63) // 64), "achieved_TBps": wbytes * ((B + 63) // 64) / (kern_ms * 1e-3) / 1e12,
                 "peak_TBps": 34.5, "frac_of_l2_peak": wbytes * ((B + 63) // 64) / (kern_ms * 1e-3) / 1e12 / 34.5,
                 "per_cu_bytes_per_clk_at_1p76GHz": wbytes * ((B + 63) // 64) / (kern_ms * 1e-3) / 256 / 1.76e9,
-                "note": "weights only (x and the hand-overs inside LDS are not in it); peak = MI355X_MICROARCH.md's aggregate L2 rate; a CU of this kernel takes in "
-                        "31-35 B/clk from L2 under MFMA + LDS load (stamps, DESIGN.md A.2), 46-51 in a bare stream (profiles/r03_l1_stream_probe.txt): the tile's "
-                        "9.6 MB at 33 B/clk are 290 k of its ~330 k cycles (the figure here is the mean over the whole launch, tail and barriers included)"}
+                "note": "weights only (x and the hand-overs inside LDS are not in it); peak = MI355X_MICROARCH.md's aggregate L2 rate.  The L1 / L2 counters "
+                        "(profiles/r05l1_summary.md) put the rate at which this kernel -- and the bf16 one -- is served at 0.23 128-byte lines per cycle and CU "
+                        "(30 B/clk, x included) whatever the queue depth, against 0.37 for a bare all-hit stream: the L2's rate under the kernel's own miss stream "
+                        "(x in both layer-0 passes, the weight stream once per XCD and tile round).  A tile's 86 k line requests at that rate are its ~330 k cycles"}
             roof_extra = {"l2_to_cu_weight_stream": l2_stream, "executed_flop_per_launch": SPLIT_PRODUCTS * B * FLOP_PER_FACE[F],
                           "executed_frac": SPLIT_PRODUCTS * achieved / peak,
                           "note": "each algorithmic product runs as 3 f16 MFMA products (hi*hi + hi*lo + lo*hi, f32 accumulate); "
