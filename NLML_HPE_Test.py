@@ -72,14 +72,13 @@ def NLML_HPE_Tester(argv=None):
     start, stop, _ = shard_bounds(n_total, world, rank)
     batch = int(args.batch or cfg.get("batch_size", 65536))
     t0 = time.time()
-    poses, valids = [], []
-    for b0 in range(start, stop, batch):
-        raw = torch.from_numpy(raw_all[b0:min(b0 + batch, stop)]).to(device)
-        pose, valid = model.from_landmarks(raw, normalize=True, return_valid=True)
-        poses.append(pose)
-        valids.append(valid)
-    pose = torch.cat(poses) if poses else torch.zeros((0, 3), device=device)
-    valid = torch.cat(valids) if valids else torch.zeros((0,), dtype=torch.bool, device=device)
+    if stop > start:
+        # host-resident landmarks: copies overlapped with the kernel, straight out of the loaded array where it can be page-locked in place
+        from nlml_hpe_amd.pipeline import HostPipeline
+        pose_np, valid_np = HostPipeline(model, batch=min(batch, stop - start)).run(raw_all[start:stop])
+        pose, valid = torch.from_numpy(pose_np).to(device), torch.from_numpy(valid_np).to(device)
+    else:
+        pose, valid = torch.zeros((0, 3), device=device), torch.zeros((0,), dtype=torch.bool, device=device)
     if world > 1:
         pose = gather_poses(pose, n_total)
         valid = gather_poses(valid.float().unsqueeze(1).expand(-1, 3).contiguous(), n_total)[:, 0] > 0.5

@@ -704,7 +704,9 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     pipe.run(raw_host)
     dt = time.perf_counter() - t0
     ex["host_resident_pcie_inclusive"] = {"faces_per_sec": B / dt, "gb_per_s_h2d": B * 5616 / dt / 1e9, "timing": "host wall clock around one run over the 65,536 faces, after a 32,768-face warm-up run",
-                                          "note": "host numpy -> pinned -> H2D (copy stream) -> fused kernel -> D2H, double-buffered"}
+                                          "h2d_form": pipe.last_mode,
+                                          "note": "host numpy -> H2D on a copy stream (the caller's array page-locked in place and read by the DMA directly when that is fast, "
+                                                  "else staged through pinned buffers: h2d_form says which) -> fused kernel -> D2H, double-buffered"}
     # BASELINE config 5 (per GPU): 64 concurrent streams, one tick = 64 raw-landmark sets -> smoothed pose + axes
     from nlml_hpe_amd.video import GraphedTick, VideoPoseTracker
     S, T = 64, 300

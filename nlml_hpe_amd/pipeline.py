@@ -2,9 +2,16 @@
 
 The ABI works on device buffers; when a caller's landmarks live in host memory (an .npz of a whole
 validation set, frames arriving from decoders) the batches are double-buffered: while the fused kernel
-runs batch i on the compute stream, batch i+1 is copied host->device on a copy stream out of pinned
-staging memory, and the [B,3] poses are copied back on the copy stream as well.  PCIe (~63 GB/s spec) caps
-this path at about 11 M faces/s (5.6 KB per face), below the kernel's rate, so the overlap matters.
+runs batch i on the compute stream, batch i+1 is copied host->device on a copy stream, and the [B,3] poses
+are copied back on the copy stream as well.  PCIe (~63 GB/s spec, 57 GB/s measured from pinned memory) caps
+this path at about 10 M faces/s (5.6 KB per face), below the kernel's rate, so the overlap matters.
+
+Where the bytes are copied from (round 5, tools/host_copy_probe.py on the GPU box): page-locking the CALLER'S array in place
+(hipHostRegister) took 0.8 ms for 368 MB there and the DMA then reads it at 49 GB/s with no CPU copy at all, where the staged form
+(threads copying pageable -> pinned, then the DMA) reached 37-39 GB/s end to end although either half alone is faster (130 GB/s with
+eight threads, 57 GB/s).  `inplace="auto"` (the default) therefore registers the first batch's range, and goes on in place if that ran
+at >= 20 GB/s (huge pages: it does; 4-KB pages of a cold mapping: it may not) -- otherwise, or if registration is refused (a read-only
+mapping, an already registered range), it falls back to the staged form for the rest.
 """
 from __future__ import annotations
 
@@ -16,24 +23,76 @@ import torch
 
 
 class HostPipeline:
-    def __init__(self, model, batch: int = 65536, normalize: bool = True):
+    def __init__(self, model, batch: int = 65536, normalize: bool = True, workers: int | None = None):
         self.model, self.batch, self.normalize = model, int(batch), normalize
         dev = model.device
         self.copy_stream = torch.cuda.Stream(device=dev)
-        self.pin_in = [torch.empty((self.batch, 468, 3), dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.pin_in = None                      # the staging buffers of the staged form: allocated when that form first runs
         self.dev_in = [torch.empty((self.batch, 468, 3), dtype=torch.float32, device=dev) for _ in range(2)]
         self.pin_out = [torch.empty((self.batch, 3), dtype=torch.float32).pin_memory() for _ in range(2)]
         self.pin_valid = [torch.empty((self.batch,), dtype=torch.bool).pin_memory() for _ in range(2)]
         # the pageable -> pinned staging copy is a plain memcpy; one thread moves ~5 GB/s, so it is split over a few
         # threads (numpy releases the GIL while copying) to keep up with the PCIe link
-        self.workers = max(1, min(8, (os.cpu_count() or 2) // 2))
+        self.workers = int(workers) if workers else max(1, min(8, (os.cpu_count() or 2) // 2))
         self.pool = ThreadPoolExecutor(self.workers)
-        self.pin_in_np = [t.numpy() for t in self.pin_in]
+        self.pin_in_np = None
+        self.last_mode = None
 
-    def run(self, raw: np.ndarray):
-        """raw f32[N,468,3] (host) -> (pose f32[N,3] radians, valid bool[N]) as numpy arrays."""
+    def _ensure_staging(self):
+        if self.pin_in is None:
+            self.pin_in = [torch.empty((self.batch, 468, 3), dtype=torch.float32).pin_memory() for _ in range(2)]
+            self.pin_in_np = [t.numpy() for t in self.pin_in]
+
+    # ---- in-place form: the caller's array page-locked where it lies
+    @staticmethod
+    def _register(arr: np.ndarray) -> bool:
+        try:
+            rc = torch.cuda.cudart().cudaHostRegister(arr.ctypes.data, arr.nbytes, 0)
+            return int(rc) == 0
+        except Exception:   # noqa: BLE001 -- (a runtime that refuses raises instead of returning a code)
+            return False
+
+    @staticmethod
+    def _unregister(arr: np.ndarray) -> None:
+        try:
+            torch.cuda.cudart().cudaHostUnregister(arr.ctypes.data)
+        except Exception:   # noqa: BLE001
+            pass
+
+    def run(self, raw: np.ndarray, inplace: str | bool = "auto"):
+        """raw f32[N,468,3] (host) -> (pose f32[N,3] radians, valid bool[N]) as numpy arrays.
+        inplace: "auto" (page-lock the caller's array in place when that is fast, see the module docstring), True (always try), False (staged)."""
+        import time
         raw = np.ascontiguousarray(raw, dtype=np.float32)
         n = raw.shape[0]
+        self.last_mode = "staged"
+        registered = []
+        if inplace and n > 0 and raw.flags.writeable:
+            m0 = min(self.batch, n)
+            t0 = time.perf_counter()
+            first = raw[:m0]
+            if self._register(first):
+                dt = time.perf_counter() - t0
+                fast = inplace is True or first.nbytes / max(dt, 1e-9) >= 20e9
+                if fast and m0 == n:
+                    registered.append(first)
+                    self.last_mode = "in place"
+                else:
+                    self._unregister(first)          # (two ranges that meet inside a page cannot both be registered: one call for the whole array)
+                    if fast and self._register(raw):
+                        registered.append(raw)
+                        self.last_mode = "in place"
+        try:
+            return self._run(raw, n, self.last_mode == "in place")
+        finally:
+            if registered:
+                torch.cuda.synchronize(self.model.device)
+                for a in registered:
+                    self._unregister(a)
+
+    def _run(self, raw: np.ndarray, n: int, in_place: bool):
+        if not in_place:
+            self._ensure_staging()
         pose = np.empty((n, 3), np.float32)
         valid = np.empty((n,), bool)
         compute = torch.cuda.current_stream(self.model.device)
@@ -49,13 +108,17 @@ class HostPipeline:
             if i >= 2:
                 d2h_done[i - 2].synchronize()      # the slot's previous outputs were read back
                 k_done[i - 2].synchronize()        # and its device input is no longer being read
-            step = (m + self.workers - 1) // self.workers
-            futs = [self.pool.submit(np.copyto, self.pin_in_np[slot][a:min(a + step, m)], raw[b0 + a:b0 + min(a + step, m)])
-                    for a in range(0, m, step)]
-            for f in futs:
-                f.result()
+            if in_place:   # DMA straight out of the caller's (now page-locked) array
+                src = torch.from_numpy(raw[b0:b0 + m])
+            else:
+                step = (m + self.workers - 1) // self.workers
+                futs = [self.pool.submit(np.copyto, self.pin_in_np[slot][a:min(a + step, m)], raw[b0 + a:b0 + min(a + step, m)])
+                        for a in range(0, m, step)]
+                for f in futs:
+                    f.result()
+                src = self.pin_in[slot][:m]
             with torch.cuda.stream(self.copy_stream):
-                self.dev_in[slot][:m].copy_(self.pin_in[slot][:m], non_blocking=True)
+                self.dev_in[slot][:m].copy_(src, non_blocking=True)
                 h2d_done[i].record(self.copy_stream)
 
         outs = [None] * len(starts)

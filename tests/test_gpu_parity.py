@@ -551,6 +551,18 @@ def test_host_pipeline_overlapped_copies(head_sds, device):
     assert not valid[123]
     pose2, _ = pipe.run(raw[:10])           # reuse with a short tail
     assert np.array_equal(pose2, pose[:10])
+    # both forms of the host -> device copy give the same bits: staged through pinned memory, and straight out of the caller's array
+    # page-locked in place; a read-only array cannot be registered for the DMA here and falls back to the staged form
+    for inplace, want_mode in ((False, "staged"), (True, "in place")):
+        p3, v3 = pipe.run(raw, inplace=inplace)
+        assert pipe.last_mode == want_mode
+        assert np.array_equal(p3, pose) and np.array_equal(v3, valid)
+    ro = raw.copy()
+    ro.setflags(write=False)
+    p4, v4 = pipe.run(ro)
+    assert pipe.last_mode == "staged" and np.array_equal(p4, pose) and np.array_equal(v4, valid)
+    p5, _ = pipe.run(raw[1:4000], inplace=True)     # a range that starts and ends inside pages, registered again right after
+    assert np.array_equal(p5, pose[1:4000])
 
 
 def test_graphed_video_tick_matches_eager(head_sds, device):
