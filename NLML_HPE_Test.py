@@ -75,7 +75,7 @@ def NLML_HPE_Tester(argv=None):
     if stop > start:
         # host-resident landmarks: copies overlapped with the kernel, straight out of the loaded array where it can be page-locked in place
         from nlml_hpe_amd.pipeline import HostPipeline
-        pose_np, valid_np = HostPipeline(model, batch=min(batch, stop - start)).run(raw_all[start:stop])
+        pose_np, valid_np = HostPipeline(model, batch=min(batch, 8192, stop - start)).run(raw_all[start:stop])
         pose, valid = torch.from_numpy(pose_np).to(device), torch.from_numpy(valid_np).to(device)
     else:
         pose, valid = torch.zeros((0, 3), device=device), torch.zeros((0,), dtype=torch.bool, device=device)

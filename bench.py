@@ -697,7 +697,7 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     from nlml_hpe_amd.model import HIPPoseModel
     from nlml_hpe_amd.pipeline import HostPipeline
     mdl = HIPPoseModel(sd1404, heads, device=dev)
-    pipe = HostPipeline(mdl, batch=16384)
+    pipe = HostPipeline(mdl, batch=8192)
     raw_host = raw.cpu().numpy()
     pipe.run(raw_host[:32768])
     t0 = time.perf_counter()

@@ -3,15 +3,16 @@
 The ABI works on device buffers; when a caller's landmarks live in host memory (an .npz of a whole
 validation set, frames arriving from decoders) the batches are double-buffered: while the fused kernel
 runs batch i on the compute stream, batch i+1 is copied host->device on a copy stream, and the [B,3] poses
-are copied back on the copy stream as well.  PCIe (~63 GB/s spec, 57 GB/s measured from pinned memory) caps
+are copied back on a third stream.  PCIe (~63 GB/s spec, 57 GB/s measured from pinned memory) caps
 this path at about 10 M faces/s (5.6 KB per face), below the kernel's rate, so the overlap matters.
 
-Where the bytes are copied from (round 5, tools/host_copy_probe.py on the GPU box): page-locking the CALLER'S array in place
-(hipHostRegister) took 0.8 ms for 368 MB there and the DMA then reads it at 49 GB/s with no CPU copy at all, where the staged form
-(threads copying pageable -> pinned, then the DMA) reached 37-39 GB/s end to end although either half alone is faster (130 GB/s with
-eight threads, 57 GB/s).  `inplace="auto"` (the default) therefore registers the first batch's range, and goes on in place if that ran
-at >= 20 GB/s (huge pages: it does; 4-KB pages of a cold mapping: it may not) -- otherwise, or if registration is refused (a read-only
-mapping, an already registered range), it falls back to the staged form for the rest.
+Where the bytes are copied from (round 5, tools/host_stage_timeline.py / host_copy_probe.py on the GPU box): the staged form -- eight threads
+copying pageable -> pinned at 85-100 GB/s while the DMA of the previous batch reads the other pinned buffer at 57 GB/s -- runs at 54 GB/s
+end to end once staging and DMA really overlap (rounds 2-4 serialised them through an event behind the next batch's H2D: 33-38 GB/s).
+Page-locking the CALLER'S array in place (hipHostRegister) and letting the DMA read it directly is as fast (56 GB/s) and needs no CPU
+copy, but the registration costs what the memory's pages make it cost: 2.7 ms per 1.5 GB on huge pages (numpy's mmap'd arrays), 55 ms
+on 4-KB pages (torch's CPU allocator).  `inplace="auto"` (the default) registers the first batch's range and goes on in place only if
+that ran at >= 200 GB/s; a refused registration (read-only mapping, a range registered already) also means the staged form.
 """
 from __future__ import annotations
 
@@ -23,10 +24,13 @@ import torch
 
 
 class HostPipeline:
-    def __init__(self, model, batch: int = 65536, normalize: bool = True, workers: int | None = None):
+    def __init__(self, model, batch: int = 8192, normalize: bool = True, workers: int | None = None):
+        # (8,192 faces = 46 MB per batch: 0.8 ms of DMA against 0.15 ms of kernel, and a 65,536-face call already has eight batches to overlap:
+        # 8.7 M faces/s where one 65,536-face batch -- nothing to overlap -- gives 5.6 M; tools/host_pipeline_sweep.py)
         self.model, self.batch, self.normalize = model, int(batch), normalize
         dev = model.device
         self.copy_stream = torch.cuda.Stream(device=dev)
+        self.out_stream = torch.cuda.Stream(device=dev)     # poses back to the host: not behind the next batch's landmarks
         self.pin_in = None                      # the staging buffers of the staged form: allocated when that form first runs
         self.dev_in = [torch.empty((self.batch, 468, 3), dtype=torch.float32, device=dev) for _ in range(2)]
         self.pin_out = [torch.empty((self.batch, 3), dtype=torch.float32).pin_memory() for _ in range(2)]
@@ -73,7 +77,7 @@ class HostPipeline:
             first = raw[:m0]
             if self._register(first):
                 dt = time.perf_counter() - t0
-                fast = inplace is True or first.nbytes / max(dt, 1e-9) >= 20e9
+                fast = inplace is True or first.nbytes / max(dt, 1e-9) >= 200e9
                 if fast and m0 == n:
                     registered.append(first)
                     self.last_mode = "in place"
@@ -105,9 +109,12 @@ class HostPipeline:
             b0 = starts[i]
             m = min(self.batch, n - b0)
             slot = i & 1
-            if i >= 2:
-                d2h_done[i - 2].synchronize()      # the slot's previous outputs were read back
-                k_done[i - 2].synchronize()        # and its device input is no longer being read
+            # (Round 5: until then this waited on the host for d2h_done[i - 2] -- an event that sat BEHIND the next batch's H2D on the one copy
+            # stream, so the staging copy of batch i + 1 only began when the H2D of batch i had ended: staging and DMA ran one after the
+            # other, 33-38 GB/s.  Now the host waits only for the pinned slot's own previous H2D, the device buffer's release is a
+            # stream-side wait, and the outputs travel on a stream of their own: 54 GB/s.)
+            if i >= 2 and not in_place:
+                h2d_done[i - 2].synchronize()      # the pinned slot's previous contents have been read by the DMA
             if in_place:   # DMA straight out of the caller's (now page-locked) array
                 src = torch.from_numpy(raw[b0:b0 + m])
             else:
@@ -118,6 +125,8 @@ class HostPipeline:
                     f.result()
                 src = self.pin_in[slot][:m]
             with torch.cuda.stream(self.copy_stream):
+                if i >= 2:
+                    self.copy_stream.wait_event(k_done[i - 2])   # the device slot is no longer being read by batch i - 2's kernel
                 self.dev_in[slot][:m].copy_(src, non_blocking=True)
                 h2d_done[i].record(self.copy_stream)
 
@@ -133,11 +142,11 @@ class HostPipeline:
             p, v = self.model.from_landmarks(self.dev_in[slot][:m], self.normalize, return_valid=True)
             k_done[i].record(compute)
             outs[i] = (p, v)
-            with torch.cuda.stream(self.copy_stream):
-                self.copy_stream.wait_event(k_done[i])
+            with torch.cuda.stream(self.out_stream):
+                self.out_stream.wait_event(k_done[i])
                 self.pin_out[slot][:m].copy_(p, non_blocking=True)
                 self.pin_valid[slot][:m].copy_(v, non_blocking=True)
-                d2h_done[i].record(self.copy_stream)
+                d2h_done[i].record(self.out_stream)
             if i >= 1:                              # drain batch i-1 while batch i runs
                 j = i - 1
                 d2h_done[j].synchronize()
