@@ -162,7 +162,7 @@ def spawn_ranks(n: int, script: str = None, argv: list = None) -> int:
 
 # the kernels of one K2 step (every kernel of the library's nlml:: namespace that a forward launches)
 K2_KERNEL_MARKS = ("encoder_heads_", "prepass_kernel", "layer_kernel", "tail_kernel", "tail_encoder_kernel", "head_kernel",
-                   "wide_layers_kernel", "wide_pass_kernel", "tail64_kernel")
+                   "wide_layers_kernel", "wide_pass_kernel", "tail64_kernel", "tail_ws_kernel")
 
 
 def expected_k2_launches(mode: str, layered: bool) -> int:
@@ -616,6 +616,18 @@ def extra_workloads(ops, synth, weights, dev, heads, sd1404, raw, feats, B):
     ex["k2_f16x2s_features_F1404"] = k2(lambda: ops.encoder_heads_fwd(feats, blob_hxs, 1404), 1404, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
     blob136_hxs = torch.from_numpy(weights.pack_blob(sd136, heads, _lib.MODE_F16X2S)).to(dev)
     ex["k2_f16x2s_features_F136"] = k2(lambda: ops.encoder_heads_fwd(x136, blob136_hxs, 136), 136, PEAK_F16_MFMA_TFLOPS, SPLIT_PRODUCTS)
+    # The same forward as trunk launch + streamed tail launch (nlml_landmarks_to_pose_streamed: bit-identical, opt-in), alternating with the
+    # fused kernel in this process: what taking the tail out of the tile buys.  The trunk launch alone costs ~0.90 of the fused kernel --
+    # its share of the L2 -> CU bytes -- which is the measurement behind "the fused kernel's time is its L2 traffic" (DESIGN.md section 3).
+    ab = {"fused_ms": [], "streamed_ms": []}
+    for _ in range(2):
+        ab["fused_ms"].append(time_kernel(lambda: ops.landmarks_to_pose(raw, blob_hxs, True), 100, warm=30))
+        ab["streamed_ms"].append(time_kernel(lambda: ops.landmarks_to_pose_streamed(raw, blob_hxs, True), 100, warm=30))
+    same = bool(torch.equal(ops.landmarks_to_pose(raw, blob_hxs, True), ops.landmarks_to_pose_streamed(raw, blob_hxs, True)))
+    ms_f, ms_s = float(np.mean(ab["fused_ms"])), float(np.mean(ab["streamed_ms"]))
+    ex["k2_f16x2s_streamed_tail_F1404"] = {"faces_per_sec": B / ms_s * 1e3, "fused_faces_per_sec_same_run": B / ms_f * 1e3, "speedup_vs_fused": ms_f / ms_s,
+                                           "bit_identical_to_fused": same, **ab, "timing": EV.format(n=100, w=30) + ", fused / streamed alternating twice",
+                                           "note": "opt-in (explicit entry points, NLML_K2_STREAMED_MIN); not the timed step, not `value`"}
     # Batch-size sweep in the default mode, through the dispatch the host layer uses (HIPPoseModel: layer-per-launch path up to 4,096 faces,
     # fused kernel above): one forward per launch sequence, HIP events.  A forward is a chain of 11 dependent layers: the layer-per-launch
     # path costs ~45 us for ANY batch it takes (seven launches), the fused kernel one tile time (~0.15 ms) for any batch up to one round

@@ -178,9 +178,28 @@ int nlml_landmarks_to_pose_wide(const float* raw, int64_t B, int normalize,
                                 const void* blob, size_t blob_bytes, float* out, float* latent, uint8_t* valid,
                                 void* workspace, size_t ws_bytes, void* stream);
 
+/* The same forward in NLML_MODE_F16X2S as TRUNK LAUNCH + STREAMED TAIL LAUNCH (+ the f32 re-evaluation launch): layers 0-2 by the
+ * eight-wave kernel, which ends with layer 2's output in `workspace` as MFMA operand fragments (1 KB per face), then layers E3..E5 and
+ * the three heads (NLML_HPE_Model_Builder.py:45-53,76-92) by a kernel in which a wave keeps a 32-face block's activations in registers
+ * through the whole tail while the tail's 1.06 MB of weights pass through LDS once per 256 faces (csrc/encoder_heads_f16x2_tailws.hip)
+ * -- in the fused kernel they stream once per 64 faces through thirteen barrier-separated stages on half the CU's waves.
+ * MEASURED 1.2 % faster than the fused kernel at 65,536 faces (0.805 against 0.815 ms, same box; the trunk launch alone costs 0.90 of the
+ * fused kernel = its share of the L2 -> CU bytes): inside the box-to-box spread, so nothing picks it by default
+ * (NLML_K2_STREAMED_MIN=<faces> makes the _ws entry points route batches from that size on through it).
+ * Bit-identical to nlml_encoder_heads_fwd / nlml_landmarks_to_pose with the same blob.  Input layout: F % 4 == 0, rows 16-byte aligned
+ * (ldx % 4 == 0) -- else NLML_E_BADARG.  `workspace`: nlml_encoder_heads_workspace_bytes(B, F) bytes, 16-byte aligned.
+ */
+int nlml_encoder_heads_fwd_streamed(const float* x, int64_t ldx, int64_t B, int F,
+                                    const void* blob, size_t blob_bytes, float* out, float* latent, uint8_t* valid,
+                                    void* workspace, size_t ws_bytes, void* stream);
+int nlml_landmarks_to_pose_streamed(const float* raw, int64_t B, int normalize,
+                                    const void* blob, size_t blob_bytes, float* out, float* latent, uint8_t* valid,
+                                    void* workspace, size_t ws_bytes, void* stream);
+
 /* THE FORWARD WITH A WORKSPACE: picks the fastest of the paths above for the batch size and the blob's mode (split-f16 modes: the
  * layer-per-launch path up to 4,096 faces; the fused kernel otherwise and for the other modes, which ignore the workspace; the
- * 128-face-tile path only when the environment asks for it, NLML_K2_WIDE_MIN=<faces>).  Same bits whichever path runs.  For hosts that
+ * 128-face-tile path and the trunk + streamed-tail path only when the environment asks for them, NLML_K2_WIDE_MIN=<faces> /
+ * NLML_K2_STREAMED_MIN=<faces>).  Same bits whichever path runs.  For hosts that
  * want one call for every batch size; the packaged host layer makes the same choice in Python (nlml_hpe_amd/model.py, `small_batch_max`)
  * and calls the plain / _small forms, which is also what bench.py times.
  * `workspace`: at least nlml_encoder_heads_workspace_bytes(B, F) bytes (>= the _small and _wide paths' needs), 16-byte aligned.

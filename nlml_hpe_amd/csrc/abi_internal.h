@@ -36,6 +36,16 @@ int launch_encoder_heads_f16x2(const float* x, int64_t ldx, const float* raw, in
 // encoder_heads_f16x2_w8.hip (NLML_MODE_F16X2S, eight waves per workgroup: the strict-fast mode's fused kernel)
 int launch_encoder_heads_f16x2_w8(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,
                                   const void* blob, float* out, float* latent, uint8_t* valid, void* stream);
+// the same forward as TWO launches (+ the re-evaluation launch): the trunk (layers 0-2, the eight-wave kernel ending with layer 2's output
+// in `workspace`) and the streamed tail (encoder_heads_f16x2_tailws.hip: layers E3.. and the heads with the weights through LDS once per
+// 256 faces); bit-identical to the fused kernel
+bool tailws_supported(const float* x, int64_t ldx, int F);
+size_t tailws_workspace_bytes(int64_t B, int F);
+int launch_encoder_heads_f16x2_tailws(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,
+                                      const void* blob, float* out, float* latent, uint8_t* valid, void* workspace,
+                                      size_t ws_bytes, void* stream);
+// encoder_heads_f16x2_tailws.hip: h3 = layer 2's output as operand fragments, nfb 32-face blocks of it -> poses (and the latent)
+int launch_tail_ws(const void* blob, const void* h3, int64_t nfb, int64_t B, float* out, float* latent, void* stream);
 // encoder_heads_f16x2_small.hip (split-f16 mode, big layers as separate launches + one tail launch, for small batches)
 size_t small_workspace_bytes(int64_t B, int F);
 int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,

@@ -28,6 +28,8 @@ struct Args {
   float* out;
   float* latent;
   uint8_t* valid;
+  void* h3ws = nullptr;   // trunk-only launch (encoder_heads_f16x2_w8.hip, TRUNK = true): E2's output as MFMA operand fragments, read by
+                          // the streamed tail (encoder_heads_f16x2_tailws.hip)
 };
 
 template <int ACT>
@@ -63,6 +65,30 @@ __device__ __forceinline__ void swap_halves(unsigned& a, unsigned& b) {
   const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
   a = r[0];
   b = r[1];
+}
+
+// The accumulators of ONE 32-neuron block for one 32-face block -> the NEXT layer's MFMA B operands, in registers: store_lds's arithmetic
+// (scale, activation, hi/lo split: the same values bit for bit) followed by the half-wave exchange of its 16-byte form, after which lane
+// (f, h) holds neurons 16p + 8h .. + 7 of face f -- exactly what a v_mfma_f32_32x32x16_f16 reads as its B operand in K step p of the
+// block (the bytes a consumer's ds_read_b128 would find at (row f, column 16p + 8h) of the LDS image).  frag[p][0] = hi, [p][1] = lo.
+template <int ACT>
+__device__ __forceinline__ void frags_from_acc(const f32x16& acc, float inv, h8 (&frag)[2][2]) {
+  typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = activate<ACT>(acc[8 * p + e] * inv);
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
+    swap_halves(hi[0], hi[2]);
+    swap_halves(hi[1], hi[3]);
+    swap_halves(lo[0], lo[2]);
+    swap_halves(lo[1], lo[3]);
+    frag[p][0] = __builtin_bit_cast(h8, u4_{hi[0], hi[1], hi[2], hi[3]});
+    frag[p][1] = __builtin_bit_cast(h8, u4_{lo[0], lo[1], lo[2], lo[3]});
+  }
 }
 
 template <int NB, int NFB>

@@ -356,7 +356,10 @@ __device__ __forceinline__ void stage_e0_pass_w8(const Ctx& c, const Args& a, in
 #define W8S_WALL(i) do { } while (0)
 #endif
 
-template <bool VEC4, bool NORM>
+// TRUNK = true (round 5, second half): the launch ends with layer 2 -- its output goes to a.h3ws as MFMA operand fragments
+// ([32-face block][K16 step][piece][lane] x 16 bytes: 1 KB per face) and the rest of the network runs as its own launch with the
+// weights streaming through LDS ONCE per 256 faces (encoder_heads_f16x2_tailws.hip).  All eight waves work to the end of this launch.
+template <bool VEC4, bool NORM, bool TRUNK = false>
 __global__ __launch_bounds__(512) void encoder_heads_f16x2_w8_kernel(Args a) {
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
 
@@ -447,6 +450,21 @@ __global__ __launch_bounds__(512) void encoder_heads_f16x2_w8_kernel(Args a) {
     kloop<1, 2, 32, WSTEP2>(acc2, acc2s, w2, c.lds + O_H2 + (c.f * S_H2 + 8 * c.h) * 2, P_H2, 32 * S_H2 * 2);
     add_acc<1, 2>(acc2, acc2s);
     W8S(10);
+    if constexpr (TRUNK) {   // h3 = relu(E2) straight from the accumulators to the hand-over buffer (no LDS image, no barrier)
+      typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+      u4_* const dst = reinterpret_cast<u4_*>(a.h3ws) + (size_t)blockIdx.x * (2 * 16 * 2 * 64) + c.lane;
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb) {
+        h8 fr[2][2];
+        frags_from_acc<ACT_RELU>(acc2[0][fb], c.hdr.inv_scale[ST_E2], fr);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc)
+            dst[((fb * 16 + 4 * jw + 2 * nbh + p) * 2 + pc) * 64] = __builtin_bit_cast(u4_, fr[p][pc]);
+      }
+      return;
+    }
     tail_pre_e3<false>(ct, acc3, wr3);                    // E3's global fetches in front of the store and the barriers
     __syncthreads();
     job_store<1, 2, ACT_RELU>(c, acc2, O_H3, P_H3, S_H3, 64 * jw + 32 * nbh, 0, c.hdr.inv_scale[ST_E2]);
@@ -473,6 +491,41 @@ __global__ __launch_bounds__(512) void encoder_heads_f16x2_w8_kernel(Args a) {
 }
 
 }  // namespace hx
+
+// ---- the strict-fast forward as trunk launch + streamed tail launch (+ the f32 re-evaluation launch) -------------------------------
+bool tailws_supported(const float* x, int64_t ldx, int F) {
+  return (F % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+}
+size_t tailws_workspace_bytes(int64_t B, int F) {
+  if (B <= 0 || F <= 0) return 0;
+  return (size_t)((B + TILE_FACES - 1) / TILE_FACES) * (2 * 16 * 2 * 1024);   // 1 KB per face of whole 64-face tiles
+}
+
+int launch_encoder_heads_f16x2_tailws(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,
+                                      const void* blob, float* out, float* latent, uint8_t* valid, void* workspace,
+                                      size_t ws_bytes, void* stream) {
+  if (B == 0) return 0;
+  if (!workspace || ws_bytes < tailws_workspace_bytes(B, F)) return fail(NLML_E_BADARG, "streamed-tail path: workspace too small");
+  if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail(NLML_E_BADARG, "streamed-tail path: workspace must be 16-byte aligned");
+  hx::Args a;
+  a.B = B; a.F = F; a.blob = blob; a.out = out; a.latent = latent; a.valid = valid; a.norm = 0; a.h3ws = workspace;
+  if (raw) {
+    a.x = raw; a.ldx = NLML_F_REFERENCE; a.norm = normalize ? 1 : 0;
+  } else {
+    a.x = x; a.ldx = ldx;
+  }
+  if (!tailws_supported(a.x, a.ldx, F)) return fail(NLML_E_BADARG, "streamed-tail path: x must be 16-byte aligned with F and ldx multiples of 4");
+  const int64_t ntiles = (B + TILE_FACES - 1) / TILE_FACES;
+  const dim3 grid((unsigned)ntiles), block(512);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a.norm) hipLaunchKernelGGL((hx::encoder_heads_f16x2_w8_kernel<true, true, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((hx::encoder_heads_f16x2_w8_kernel<true, false, true>), grid, block, 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+  if (int rc = launch_tail_ws(blob, workspace, 2 * ntiles, B, out, latent, stream)) return rc;
+  return launch_encoder_heads_f32(x, ldx, raw, normalize, B, F, static_cast<const char*>(blob) + strict_f32_image_offset(F), out, latent,
+                                  nullptr, nullptr, nullptr, stream, STRICT_INKERNEL_RESCUE_MAX);
+}
 
 int launch_encoder_heads_f16x2_w8(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,
                                   const void* blob, float* out, float* latent, uint8_t* valid, void* stream) {

@@ -100,6 +100,7 @@ def test_launch_entry_points_validate_before_touching_the_gpu():
     assert L.nlml_encoder_heads_workspace_bytes(129, 1404) == 2 * (88 * 4 * 128 + 256 * 128) * 16       # two 128-face tiles: input quads + layer-0 output quads
     assert L.nlml_landmarks_to_pose_ws(None, -1, 1, None, 0, None, None, None, None, 0, None) == -1
     assert L.nlml_landmarks_to_pose_wide(None, 5, 1, None, 0, None, None, None, None, 0, None) == -1 and b"null" in L.nlml_last_error()
+    assert L.nlml_landmarks_to_pose_streamed(None, 5, 1, None, 0, None, None, None, None, 0, None) == -1 and b"null" in L.nlml_last_error()
     assert L.nlml_tucker_objective(None, None, 1404, None, None, None, 0, None, None, None) == 0
 
 

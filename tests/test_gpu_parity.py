@@ -1622,6 +1622,100 @@ def test_strict_reevaluation_launch_in_its_wide_form_with_flagged_faces(path, he
     assert torch.equal(o, o_fused)                                                          # both paths, one answer
 
 
+# ---- round 5, second half: the trunk launch + streamed tail launch (encoder_heads_f16x2_w8.hip TRUNK = true, encoder_heads_f16x2_tailws.hip)
+@pytest.mark.parametrize("B", [1, 31, 64, 65, 257, 700, 4096 + 37, 16384, 65536 - 63])
+def test_streamed_tail_path_is_bit_identical_to_the_fused_kernel(B, head_sds, device):
+    """Layers 0-2 by the eight-wave kernel ending with layer 2's output in a workspace as MFMA operand fragments, then E3..E5 and the heads by
+    the streamed-tail kernel (a wave keeps a 32-face block's activations in registers, the weights pass through LDS once per 256 faces):
+    pose, latent and the "no face" mask bit for bit against the fused kernel -- raw landmarks (normalised in the launch and not), features,
+    partial 32-face blocks, partial workgroups of the tail kernel (B not a multiple of 256), waves beyond the batch."""
+    sd = synth.encoder_state_dict(1404, seed=0)
+    blob = _blob_hx(sd, head_sds, device, "f16x2s")
+    raw_np = synth.raw_landmarks(B, seed=6)
+    if B >= 65:
+        raw_np[7] = 0.0                       # a "no face" row
+        raw_np[B - 1] = raw_np[3]             # (and a duplicate in the last, partial, tile)
+    raw = torch.from_numpy(raw_np).to(device)
+    for normalize in (True, False):
+        o, l, v = ops.landmarks_to_pose(raw, blob, normalize, return_latent=True, return_valid=True)
+        o2, l2, v2 = _wide_call("nlml_landmarks_to_pose_streamed", raw, B, blob, device, extra=(B, int(normalize)))
+        assert torch.equal(o, o2) and torch.equal(l, l2) and torch.equal(v.to(torch.uint8), v2), (B, normalize)
+        o4, _, _ = _wide_call("nlml_landmarks_to_pose_streamed", raw, B, blob, device, extra=(B, int(normalize)), want_latent=False, want_valid=False)
+        assert torch.equal(o, o4)             # (no latent, no mask asked for)
+    feats = ops.normalize_ipd(raw, True)
+    o, l, v = ops.encoder_heads_fwd(feats, blob, 1404, return_latent=True, return_valid=True)
+    o3, l3, v3 = _wide_call("nlml_encoder_heads_fwd_streamed", feats, B, blob, device, extra=(feats.stride(0) if B > 1 else 1404, B, 1404))
+    assert torch.equal(o, o3) and torch.equal(l, l3) and torch.equal(v.to(torch.uint8), v3)
+
+
+def test_streamed_tail_path_with_the_shipped_heads_and_a_padded_row_stride(head_sds, device):
+    """Features with a row stride larger than F (ldx = 1,408) through the trunk launch, and the layer-per-launch path as a third opinion."""
+    sd = synth.encoder_state_dict(1404, seed=3)
+    blob = _blob_hx(sd, head_sds, device, "f16x2s")
+    B = 1000
+    buf = torch.zeros((B, 1408), dtype=torch.float32, device=device)
+    buf[:, :1404] = torch.from_numpy(synth.features(B, 1404, seed=12)).to(device)
+    x = buf[:, :1404]
+    want = ops.encoder_heads_fwd(x, blob, 1404, return_latent=True)
+    o, l, _ = _wide_call("nlml_encoder_heads_fwd_streamed", x, B, blob, device, extra=(1408, B, 1404), want_valid=False)
+    assert torch.equal(want[0], o) and torch.equal(want[1], l)
+    small = ops.encoder_heads_fwd_small(x, blob, 1404, return_latent=True)
+    assert torch.equal(small[0], o) and torch.equal(small[1], l)
+
+
+def test_streamed_tail_path_refuses_what_it_does_not_take(head_sds, device):
+    """Strict-fast blob only, 16-byte aligned rows with F % 4 == 0, a workspace of the documented size: anything else is NLML_E_BADARG."""
+    from nlml_hpe_amd import _lib
+    L = _lib.lib()
+    sd = synth.encoder_state_dict(1404, seed=0)
+    raw = torch.from_numpy(synth.raw_landmarks(256, seed=8)).to(device)
+    st = torch.cuda.current_stream(device).cuda_stream
+    blob_fast = torch.from_numpy(weights.pack_blob(sd, head_sds, _lib.MODE_F16X2)).to(device)
+    with pytest.raises(_lib.NlmlError, match="F16X2S"):
+        _wide_call("nlml_landmarks_to_pose_streamed", raw, 256, blob_fast, device, extra=(256, 1))
+    blob = _blob_hx(sd, head_sds, device, "f16x2s")
+    out = torch.empty((256, 3), dtype=torch.float32, device=device)
+    ws = torch.empty((1024,), dtype=torch.uint8, device=device)
+    rc = L.nlml_landmarks_to_pose_streamed(raw.data_ptr(), 256, 1, blob.data_ptr(), blob.numel(), out.data_ptr(), None, None, ws.data_ptr(),
+                                           ws.numel(), st)
+    assert rc == -1 and b"workspace" in L.nlml_last_error()
+    ws = torch.empty((L.nlml_encoder_heads_workspace_bytes(256, 1404),), dtype=torch.uint8, device=device)
+    assert ws.numel() >= 4 * 65536            # 1 KB per face of whole 64-face tiles
+    x = torch.from_numpy(synth.features(257, 1404, seed=2)).to(device)
+    rc = L.nlml_encoder_heads_fwd_streamed(x.data_ptr() + 4, 1404, 256, 1400, blob.data_ptr(), blob.numel(), out.data_ptr(), None, None,
+                                           ws.data_ptr(), ws.numel(), st)
+    assert rc < 0                             # (blob size does not match F = 1,400: refused before any launch)
+    rc = L.nlml_encoder_heads_fwd_streamed(x.data_ptr() + 4, 1404, 256, 1404, blob.data_ptr(), blob.numel(), out.data_ptr(), None, None,
+                                           ws.data_ptr(), ws.numel(), st)
+    assert rc == -1 and b"aligned" in L.nlml_last_error()
+    assert L.nlml_landmarks_to_pose_streamed(raw.data_ptr(), 0, 1, blob.data_ptr(), blob.numel(), out.data_ptr(), None, None, None, 0, st) == 0
+
+
+def test_streamed_tail_path_flagged_faces_go_to_the_reevaluation_launch(head_sds, device):
+    """A face beyond f16's range leaves the streamed tail with a non-finite pose, exactly as it leaves the fused kernel, and the f32
+    re-evaluation launch behind it rewrites its tile: flagged faces = the strict parity kernel's bits, the others untouched, same answer as
+    the fused path (16,384 - 63 faces: the re-evaluation launch in its 64-face-tile form)."""
+    F, B = 1404, 16384 - 63
+    sd = synth.encoder_state_dict(F, seed=0)
+    blob = _blob_hx(sd, head_sds, device, "f16x2s")
+    blob32 = torch.from_numpy(weights.pack_blob(sd, head_sds)).to(device)
+    x = synth.features(B, F, seed=78)
+    flagged = np.zeros(B, bool)
+    flagged[64 * 3 + 33] = True
+    flagged[64 * 120:64 * 121] = True
+    flagged[B - 2:] = True
+    bad = x.copy()
+    bad[flagged] *= 3.4e4
+    xb = torch.from_numpy(bad).to(device)
+    o, l, _ = _wide_call("nlml_encoder_heads_fwd_streamed", xb, B, blob, device, extra=(F, B, F), want_valid=False)
+    o_f, l_f = ops.encoder_heads_fwd(xb, blob, F, return_latent=True)
+    o32, l32 = ops.encoder_heads_fwd(xb, blob32, F, return_latent=True)
+    fl = torch.from_numpy(flagged).to(device)
+    assert torch.isfinite(o).all()
+    assert torch.equal(o, o_f) and torch.equal(l, l_f)
+    assert torch.equal(o[fl], o32[fl]) and torch.equal(l[fl], l32[fl])
+
+
 needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL over xGMI (skips on the one-GPU box)")
 
 

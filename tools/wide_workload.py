@@ -1,5 +1,5 @@
 """Workload for rocprofv3: N calls of the 128-face-tile path (or the fused kernel with `fused`) on 65,536 raw-landmark faces.
-usage: wide_workload.py [wide|fused|ws] [calls] [batch] [f16x2s|bf16]"""
+usage: wide_workload.py [wide|streamed|fused|ws] [calls] [batch] [f16x2s|bf16]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,6 +22,8 @@ st = torch.cuda.current_stream().cuda_stream
 for _ in range(calls):
     if which == "wide":
         L.nlml_landmarks_to_pose_wide(raw.data_ptr(), B, 1, blob.data_ptr(), blob.numel(), out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), st)
+    elif which == "streamed":
+        L.nlml_landmarks_to_pose_streamed(raw.data_ptr(), B, 1, blob.data_ptr(), blob.numel(), out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), st)
     elif which == "ws":
         L.nlml_landmarks_to_pose_ws(raw.data_ptr(), B, 1, blob.data_ptr(), blob.numel(), out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), st)
     else:
