@@ -22,7 +22,7 @@ for f in glob.glob("$OUT/pmc_*/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         c[r["Kernel_Name"].split("(")[0][-60:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in c.items():
-    if not any(t in k for t in ("encoder_heads", "tucker", "wide_layer", "tail64")): continue
+    if not any(t in k for t in ("encoder_heads", "tucker", "wide_layer", "tail64", "tail_ws")): continue
     print(k)
     for n, v in sorted(cs.items()): print(f"   {n:32s} {sum(v)/len(v):18,.1f}  (n={len(v)})")
 for f in glob.glob("$OUT/trace/**/*_kernel_stats.csv", recursive=True):
