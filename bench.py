@@ -161,8 +161,7 @@ def spawn_ranks(n: int, script: str = None, argv: list = None) -> int:
 
 
 # the kernels of one K2 step (every kernel of the library's nlml:: namespace that a forward launches)
-K2_KERNEL_MARKS = ("encoder_heads_", "prepass_kernel", "layer_kernel", "tail_kernel", "tail_encoder_kernel", "head_kernel",
-                   "wide_layers_kernel", "wide_pass_kernel", "tail64_kernel", "tail_ws_kernel")
+K2_KERNEL_MARKS = ("encoder_heads_", "prepass_kernel", "layer_kernel", "tail_kernel", "tail_encoder_kernel", "head_kernel", "tail_ws_kernel")
 
 
 def expected_k2_launches(mode: str, layered: bool) -> int:

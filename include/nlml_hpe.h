@@ -161,23 +161,6 @@ int nlml_landmarks_to_pose_small(const float* raw, int64_t B, int normalize,
                                  const void* blob, size_t blob_bytes, float* out, float* latent, uint8_t* valid,
                                  void* workspace, size_t ws_bytes, void* stream);
 
-/* The same forward over 128-FACE tiles in NLML_MODE_F16X2S: the three big layers in passes of 256 neurons x 128 faces (eight waves per
- * workgroup, activations staged through LDS, layer outputs handed over through global memory) plus the tail per 64-face tile and the f32
- * re-evaluation launch.  A fused 64-face tile streams the 9.6 MB of weights through its CU once per 64 faces; the 128-face tile shape needs
- * 2/3 of the operand bytes per MFMA (csrc/encoder_heads_f16x2_wide.hip).  MEASURED SLOWER than the fused kernel (0.96 ms against 0.875 ms
- * per 65,536 faces: what the weights save, the hand-over through memory costs -- DESIGN.md section 3), so nothing picks it by default; it
- * is kept as a second, independent implementation of the same arithmetic.
- * Bit-identical to nlml_encoder_heads_fwd / nlml_landmarks_to_pose with the same blob.  Input layout: F % 4 == 0, rows 16-byte aligned
- * (ldx % 4 == 0), an even number of 64-column groups in layer 0 (the reference's 1,404 columns qualify) -- else NLML_E_BADARG.
- * `workspace`: nlml_encoder_heads_workspace_bytes(B, F) bytes, 16-byte aligned, contents irrelevant before and after.
- */
-int nlml_encoder_heads_fwd_wide(const float* x, int64_t ldx, int64_t B, int F,
-                                const void* blob, size_t blob_bytes, float* out, float* latent, uint8_t* valid,
-                                void* workspace, size_t ws_bytes, void* stream);
-int nlml_landmarks_to_pose_wide(const float* raw, int64_t B, int normalize,
-                                const void* blob, size_t blob_bytes, float* out, float* latent, uint8_t* valid,
-                                void* workspace, size_t ws_bytes, void* stream);
-
 /* The same forward in NLML_MODE_F16X2S as TRUNK LAUNCH + STREAMED TAIL LAUNCH (+ the f32 re-evaluation launch): layers 0-2 by the
  * eight-wave kernel, which ends with layer 2's output in `workspace` as MFMA operand fragments (1 KB per face), then layers E3..E5 and
  * the three heads (NLML_HPE_Model_Builder.py:45-53,76-92) by a kernel in which a wave keeps a 32-face block's activations in registers
@@ -198,11 +181,10 @@ int nlml_landmarks_to_pose_streamed(const float* raw, int64_t B, int normalize,
 
 /* THE FORWARD WITH A WORKSPACE: picks the fastest of the paths above for the batch size and the blob's mode (split-f16 modes: the
  * layer-per-launch path up to 4,096 faces; the fused kernel otherwise and for the other modes, which ignore the workspace; the
- * 128-face-tile path and the trunk + streamed-tail path only when the environment asks for them, NLML_K2_WIDE_MIN=<faces> /
- * NLML_K2_STREAMED_MIN=<faces>).  Same bits whichever path runs.  For hosts that
+ * trunk + streamed-tail path only when the environment asks for it, NLML_K2_STREAMED_MIN=<faces>).  Same bits whichever path runs.  For hosts that
  * want one call for every batch size; the packaged host layer makes the same choice in Python (nlml_hpe_amd/model.py, `small_batch_max`)
  * and calls the plain / _small forms, which is also what bench.py times.
- * `workspace`: at least nlml_encoder_heads_workspace_bytes(B, F) bytes (>= the _small and _wide paths' needs), 16-byte aligned.
+ * `workspace`: at least nlml_encoder_heads_workspace_bytes(B, F) bytes (>= the _small and _streamed paths' needs), 16-byte aligned.
  */
 size_t nlml_encoder_heads_workspace_bytes(int64_t B, int F);
 int nlml_encoder_heads_fwd_ws(const float* x, int64_t ldx, int64_t B, int F,

@@ -33,10 +33,6 @@ SYMBOLS = {
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "nlml_landmarks_to_pose_small": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "nlml_encoder_heads_fwd_wide": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
-                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "nlml_landmarks_to_pose_wide": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
-                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "nlml_encoder_heads_fwd_streamed": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "nlml_landmarks_to_pose_streamed": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,

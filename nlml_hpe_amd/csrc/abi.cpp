@@ -122,40 +122,23 @@ int nlml_landmarks_to_pose_small(const float* raw, int64_t B, int normalize, con
                                           ws_bytes, split, stream);
 }
 
-// ---- strict-fast mode, LARGE batches: 128-face tiles, one launch per big layer (encoder_heads_f16x2_wide.hip) ----------------
-static int check_wide(int64_t B, int F, const void* blob, size_t blob_bytes, const float* out) {
+// ---- strict-fast mode, LARGE batches: trunk launch + streamed tail launch (encoder_heads_f16x2_w8.hip TRUNK, encoder_heads_f16x2_tailws.hip) ----
+static int check_streamed(int64_t B, int F, const void* blob, size_t blob_bytes, const float* out) {
   int mode = 0;
   if (int rc = check_blob_args(B, F, blob, blob_bytes, out, &mode)) return rc;
-  if (mode != NLML_MODE_F16X2S) return fail(NLML_E_BADARG, "wide / streamed-tail path: NLML_MODE_F16X2S blob only");
+  if (mode != NLML_MODE_F16X2S) return fail(NLML_E_BADARG, "streamed-tail path: NLML_MODE_F16X2S blob only");
   return 0;
 }
-
-int nlml_encoder_heads_fwd_wide(const float* x, int64_t ldx, int64_t B, int F, const void* blob, size_t blob_bytes,
-                                float* out, float* latent, uint8_t* valid, void* workspace, size_t ws_bytes, void* stream) {
-  if (int rc = check_wide(B, F, blob, blob_bytes, out)) return rc;
-  if (B > 0 && (!x || ldx < F)) return fail(NLML_E_BADARG, "encoder_heads: null x or ldx < F");
-  return launch_encoder_heads_f16x2_wide(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, workspace, ws_bytes, stream);
-}
-
-int nlml_landmarks_to_pose_wide(const float* raw, int64_t B, int normalize, const void* blob, size_t blob_bytes,
-                                float* out, float* latent, uint8_t* valid, void* workspace, size_t ws_bytes, void* stream) {
-  if (int rc = check_wide(B, NLML_F_REFERENCE, blob, blob_bytes, out)) return rc;
-  if (B > 0 && !raw) return fail(NLML_E_BADARG, "landmarks_to_pose: null raw");
-  return launch_encoder_heads_f16x2_wide(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, workspace,
-                                         ws_bytes, stream);
-}
-
-// ---- strict-fast mode, LARGE batches: trunk launch + streamed tail launch (encoder_heads_f16x2_w8.hip TRUNK, encoder_heads_f16x2_tailws.hip) ----
 int nlml_encoder_heads_fwd_streamed(const float* x, int64_t ldx, int64_t B, int F, const void* blob, size_t blob_bytes,
                                     float* out, float* latent, uint8_t* valid, void* workspace, size_t ws_bytes, void* stream) {
-  if (int rc = check_wide(B, F, blob, blob_bytes, out)) return rc;
+  if (int rc = check_streamed(B, F, blob, blob_bytes, out)) return rc;
   if (B > 0 && (!x || ldx < F)) return fail(NLML_E_BADARG, "encoder_heads: null x or ldx < F");
   return launch_encoder_heads_f16x2_tailws(x, ldx, nullptr, 0, B, F, blob, out, latent, valid, workspace, ws_bytes, stream);
 }
 
 int nlml_landmarks_to_pose_streamed(const float* raw, int64_t B, int normalize, const void* blob, size_t blob_bytes,
                                     float* out, float* latent, uint8_t* valid, void* workspace, size_t ws_bytes, void* stream) {
-  if (int rc = check_wide(B, NLML_F_REFERENCE, blob, blob_bytes, out)) return rc;
+  if (int rc = check_streamed(B, NLML_F_REFERENCE, blob, blob_bytes, out)) return rc;
   if (B > 0 && !raw) return fail(NLML_E_BADARG, "landmarks_to_pose: null raw");
   return launch_encoder_heads_f16x2_tailws(nullptr, 0, raw, normalize, B, NLML_F_REFERENCE, blob, out, latent, valid, workspace,
                                            ws_bytes, stream);
@@ -164,17 +147,9 @@ int nlml_landmarks_to_pose_streamed(const float* raw, int64_t B, int normalize, 
 // ---- the forward with a caller-provided workspace: the fastest path for the batch size and the blob's mode -------------------------
 // (measured crossovers, tools/k2_crossover.py and bench.py extra.k2_batch_sweep)
 static const int64_t kSmallMax = 4096;     // split-f16 modes: up to here the layer-per-launch path over 64-face tiles
-// The 128-face-tile path (encoder_heads_f16x2_wide.hip) is bit-identical to the fused kernel and was built to beat it at large batches; measured
-// (round 5) it does not -- 0.96 ms against 0.875 ms per 65,536 faces -- so the dispatcher never picks it by
-// itself.  NLML_K2_WIDE_MIN=<faces> routes batches from that size on through it (A/B runs; the explicit _wide entry points always do).
-static int64_t wide_min() {
-  static const int64_t v = [] { const char* e = getenv("NLML_K2_WIDE_MIN"); return e && e[0] ? (int64_t)atoll(e) : (int64_t)-1; }();
-  return v;
-}
-
 // The trunk + streamed-tail path (encoder_heads_f16x2_tailws.hip) is bit-identical to the fused kernel and measured 1.2 % faster at 65,536
 // faces (0.805 against 0.815 ms, same box, alternating) -- inside the box-to-box spread, for a 64 MB workspace and a
-// second big launch -- so the dispatcher does not pick it by itself either.  NLML_K2_STREAMED_MIN=<faces> routes batches from that size
+// second big launch -- so the dispatcher does not pick it by itself.  NLML_K2_STREAMED_MIN=<faces> routes batches from that size
 // on through it (the explicit _streamed entry points always do).
 static int64_t streamed_min() {
   static const int64_t v = [] { const char* e = getenv("NLML_K2_STREAMED_MIN"); return e && e[0] ? (int64_t)atoll(e) : (int64_t)-1; }();
@@ -182,8 +157,8 @@ static int64_t streamed_min() {
 }
 
 size_t nlml_encoder_heads_workspace_bytes(int64_t B, int F) {
-  const size_t a = small_workspace_bytes(B, F), b = wide_workspace_bytes(B, F), c = tailws_workspace_bytes(B, F);
-  return a > b ? (a > c ? a : c) : (b > c ? b : c);
+  const size_t a = small_workspace_bytes(B, F), b = tailws_workspace_bytes(B, F);
+  return a > b ? a : b;
 }
 
 static int fwd_ws(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F, const void* blob, size_t blob_bytes,
@@ -196,8 +171,6 @@ static int fwd_ws(const float* x, int64_t ldx, const float* raw, int normalize, 
   const int split = mode == NLML_MODE_F16X2S;
   if (B <= kSmallMax)
     return launch_encoder_heads_f16x2_small(x, ldx, raw, normalize, B, F, blob, out, latent, valid, workspace, ws_bytes, split, stream);
-  if (split && wide_min() >= 0 && B >= wide_min() && wide_supported(raw ? raw : x, raw ? NLML_F_REFERENCE : ldx, F))
-    return launch_encoder_heads_f16x2_wide(x, ldx, raw, normalize, B, F, blob, out, latent, valid, workspace, ws_bytes, stream);
   if (split && streamed_min() >= 0 && B >= streamed_min() && tailws_supported(raw ? raw : x, raw ? NLML_F_REFERENCE : ldx, F))
     return launch_encoder_heads_f16x2_tailws(x, ldx, raw, normalize, B, F, blob, out, latent, valid, workspace, ws_bytes, stream);
   return launch_encoder_heads_f16x2(x, ldx, raw, normalize, B, F, blob, out, latent, valid, split, stream);

@@ -51,12 +51,6 @@ size_t small_workspace_bytes(int64_t B, int F);
 int launch_encoder_heads_f16x2_small(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,
                                      const void* blob, float* out, float* latent, uint8_t* valid, void* workspace,
                                      size_t ws_bytes, int split, void* stream);
-// encoder_heads_f16x2_wide.hip (NLML_MODE_F16X2S, LARGE batches: the big layers as one launch each over 128-face tiles + a tail launch)
-bool wide_supported(const float* x, int64_t ldx, int F);   // input layout the wide path takes (else: the fused kernel)
-size_t wide_workspace_bytes(int64_t B, int F);
-int launch_encoder_heads_f16x2_wide(const float* x, int64_t ldx, const float* raw, int normalize, int64_t B, int F,
-                                    const void* blob, float* out, float* latent, uint8_t* valid, void* workspace,
-                                    size_t ws_bytes, void* stream);
 // artefacts.hip
 int launch_cosine_table(const float* angles, int64_t n, const double* cos_params, int R, double* out, void* stream);
 int launch_mode5_product(const float* core, const float* U, int Q, int R5, int M, float* W, void* stream);

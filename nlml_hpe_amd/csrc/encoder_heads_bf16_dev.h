@@ -1,5 +1,5 @@
-// encoder_heads_bf16_dev.h -- device helpers of the bf16 throughput-mode kernels (encoder_heads_bf16_w8.hip: the fused eight-wave kernel;
-// encoder_heads_bf16_wide.hip: the 128-face-tile path, whose last launch runs tail_stages_bf16() below): operand types, the one-load-per-
+// encoder_heads_bf16_dev.h -- device helpers of the bf16 throughput-mode kernel (encoder_heads_bf16_w8.hip: the fused eight-wave kernel; a
+// 128-face-tile path built on them in round 5 measured slower and was deleted): operand types, the one-load-per-
 // MFMA-slot K steps, the K loops over LDS images, the bf16 store, and the network's tail (E3, E4, E5 and the three heads on both 32-face
 // blocks at once) as one function over a 64-face tile whose E2 output sits in the H3 LDS image.  512 threads.  NOT a parity path.
 #pragma once

@@ -97,9 +97,8 @@ def test_launch_entry_points_validate_before_touching_the_gpu():
     # the workspace-taking entry points (round 5): sizes on the host, argument checks before any launch
     assert L.nlml_encoder_heads_workspace_bytes(0, 1404) == 0 and L.nlml_encoder_heads_workspace_bytes(64, 0) == 0
     assert L.nlml_encoder_heads_workspace_bytes(65536, 1404) >= L.nlml_encoder_heads_small_workspace_bytes(65536, 1404)
-    assert L.nlml_encoder_heads_workspace_bytes(129, 1404) == 2 * (88 * 4 * 128 + 256 * 128) * 16       # two 128-face tiles: input quads + layer-0 output quads
+    assert L.nlml_encoder_heads_workspace_bytes(65536, 1404) >= 65536 * 1024                                 # the streamed tail's hand-over: 1 KB per face
     assert L.nlml_landmarks_to_pose_ws(None, -1, 1, None, 0, None, None, None, None, 0, None) == -1
-    assert L.nlml_landmarks_to_pose_wide(None, 5, 1, None, 0, None, None, None, None, 0, None) == -1 and b"null" in L.nlml_last_error()
     assert L.nlml_landmarks_to_pose_streamed(None, 5, 1, None, 0, None, None, None, None, 0, None) == -1 and b"null" in L.nlml_last_error()
     assert L.nlml_tucker_objective(None, None, 1404, None, None, None, 0, None, None, None) == 0
 

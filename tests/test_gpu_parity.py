@@ -1515,10 +1515,11 @@ def test_bench_two_rank_path_on_one_gpu(repo_root, device):
     assert rec["config"]["collective"].startswith("all_gather")
 
 
-# ---- round 5: the 128-face-tile path (encoder_heads_f16x2_wide.hip), the workspace-taking entry points, the wide form of the f32
-# re-evaluation launch with flagged faces, and the RCCL tests that run by themselves on the first multi-GPU box
+# ---- round 5: the workspace-taking entry points, the 64-face-tile form of the f32 re-evaluation launch with flagged faces, the trunk + streamed-tail
+# path, and the RCCL tests that run by themselves on the first multi-GPU box.  (The 128-face-tile path these tests were first written for measured
+# slower than the fused kernel and was deleted at the round's end: DESIGN.md section 3, Appendix A.5.)
 def _wide_call(fn_name, first, B, blob, device, *, want_latent=True, want_valid=True, extra=()):
-    """One call of a workspace-taking C entry point (nlml_*_wide / nlml_*_ws) -> (pose, latent, valid)."""
+    """One call of a workspace-taking C entry point (nlml_*_streamed / nlml_*_ws) -> (pose, latent, valid)."""
     from nlml_hpe_amd import _lib
     L = _lib.lib()
     F = 1404
@@ -1533,34 +1534,10 @@ def _wide_call(fn_name, first, B, blob, device, *, want_latent=True, want_valid=
     return out, lat, val
 
 
-@pytest.mark.parametrize("B", [1, 128, 129, 700, 4096 + 37, 16384])
-def test_wide_path_is_bit_identical_to_the_fused_kernel(B, head_sds, device):
-    """The 128-face-tile path -- a second, independent implementation of the strict-fast arithmetic (passes of 256 neurons x 128 faces, quad-major
-    f32 hand-over between the layers, x staged once and re-fed from a scratch buffer) -- against the fused eight-wave kernel: pose, latent and
-    the "no face" mask bit for bit, from raw landmarks (normalised in the launch and not), from features, with a partial last tile."""
-    sd = synth.encoder_state_dict(1404, seed=0)
-    blob = _blob_hx(sd, head_sds, device, "f16x2s")
-    raw_np = synth.raw_landmarks(B, seed=5)
-    if B >= 129:
-        raw_np[7] = 0.0                       # a "no face" row
-        raw_np[B - 1] = raw_np[3]             # (and a duplicate in the last, partial, tile)
-    raw = torch.from_numpy(raw_np).to(device)
-    for normalize in (True, False):
-        o, l, v = ops.landmarks_to_pose(raw, blob, normalize, return_latent=True, return_valid=True)
-        o2, l2, v2 = _wide_call("nlml_landmarks_to_pose_wide", raw, B, blob, device, extra=(B, int(normalize)))
-        assert torch.equal(o, o2) and torch.equal(l, l2) and torch.equal(v.to(torch.uint8), v2), (B, normalize)
-    feats = ops.normalize_ipd(raw, True)
-    o, l, v = ops.encoder_heads_fwd(feats, blob, 1404, return_latent=True, return_valid=True)
-    o3, l3, v3 = _wide_call("nlml_encoder_heads_fwd_wide", feats, B, blob, device, extra=(feats.stride(0) if B > 1 else 1404, B, 1404))
-    assert torch.equal(o, o3) and torch.equal(l, l3) and torch.equal(v.to(torch.uint8), v3)
-
-
-def test_wide_path_refuses_what_it_does_not_take_and_ws_entry_points_dispatch(head_sds, device):
-    """nlml_*_wide: strict-fast blob only, F % 4 == 0 rows, a workspace of the documented size -- anything else is NLML_E_BADARG, never a
-    launch.  nlml_*_ws (what the host layer may call for every batch size): same bits as the fused entry points at 64, 4,096, 4,097 and
-    9,000 faces in both split-f16 modes and in f32 (which ignores the workspace)."""
+def test_ws_entry_points_dispatch(head_sds, device):
+    """nlml_*_ws (what a host may call for every batch size): same bits as the fused entry points at 64, 4,096, 4,097 and 9,000 faces in both
+    split-f16 modes and in f32 (which ignores the workspace)."""
     from nlml_hpe_amd import _lib
-    L = _lib.lib()
     sd = synth.encoder_state_dict(1404, seed=0)
     raw = torch.from_numpy(synth.raw_landmarks(9000, seed=8)).to(device)
     for mode in ("f16x2s", "f16x2", "f32"):
@@ -1569,30 +1546,13 @@ def test_wide_path_refuses_what_it_does_not_take_and_ws_entry_points_dispatch(he
             want = ops.landmarks_to_pose(raw[:B], blob, True)
             got, _, _ = _wide_call("nlml_landmarks_to_pose_ws", raw[:B], B, blob, device, extra=(B, 1))
             assert torch.equal(want, got), (mode, B)
-    blob_fast = torch.from_numpy(weights.pack_blob(sd, head_sds, _lib.MODE_F16X2)).to(device)
-    with pytest.raises(_lib.NlmlError, match="F16X2S"):
-        _wide_call("nlml_landmarks_to_pose_wide", raw[:256], 256, blob_fast, device, extra=(256, 1))
-    blob = _blob_hx(sd, head_sds, device, "f16x2s")
-    out = torch.empty((256, 3), dtype=torch.float32, device=device)
-    ws = torch.empty((1024,), dtype=torch.uint8, device=device)
-    rc = L.nlml_landmarks_to_pose_wide(raw.data_ptr(), 256, 1, blob.data_ptr(), blob.numel(), out.data_ptr(), None, None, ws.data_ptr(), ws.numel(),
-                                       torch.cuda.current_stream(device).cuda_stream)
-    assert rc == -1 and b"workspace" in L.nlml_last_error()
-    sd136 = synth.encoder_state_dict(136, seed=0)      # 136 columns = 3 groups of 64: an odd number the wide path does not take
-    b136 = torch.from_numpy(weights.pack_blob(sd136, head_sds, _lib.MODE_F16X2S)).to(device)
-    x136 = torch.from_numpy(synth.features(256, 136, seed=2)).to(device)
-    ws = torch.empty((L.nlml_encoder_heads_workspace_bytes(256, 136),), dtype=torch.uint8, device=device)
-    rc = L.nlml_encoder_heads_fwd_wide(x136.data_ptr(), 136, 256, 136, b136.data_ptr(), b136.numel(), out.data_ptr(), None, None, ws.data_ptr(),
-                                       ws.numel(), torch.cuda.current_stream(device).cuda_stream)
-    assert rc == -1 and b"input layout" in L.nlml_last_error()
 
 
-@pytest.mark.parametrize("path", ["fused", "wide"])
-def test_strict_reevaluation_launch_in_its_wide_form_with_flagged_faces(path, head_sds, device):
+def test_strict_reevaluation_launch_in_its_wide_form_with_flagged_faces(head_sds, device):
     """behind a large batch the f32 re-evaluation launch runs 64-face tiles (two column blocks per workgroup), a form the
     flagged-face tests at <= 4,096 faces never reach.  16,384 - 63 faces (a partial last tile): one flagged face in the low half of a
     tile, a few in the high half of another, a whole tile, and the last, partial, tile -- the flagged faces take the strict parity (f32)
-    kernel's bits, pose and latent, every other face keeps the strict-fast kernel's, and the 128-face-tile path agrees bit for bit."""
+    kernel's bits, pose and latent, every other face keeps the strict-fast kernel's (the trunk + streamed-tail path: its own test below)."""
     F, B = 1404, 16384 - 63
     sd = synth.encoder_state_dict(F, seed=0)
     blob = _blob_hx(sd, head_sds, device, "f16x2s")
@@ -1607,19 +1567,15 @@ def test_strict_reevaluation_launch_in_its_wide_form_with_flagged_faces(path, he
     bad = x.copy()
     bad[flagged] *= 3.4e4                            # features to 6.8e4: beyond f16's range in layer 0
     xb = torch.from_numpy(bad).to(device)
-    if path == "fused":
-        o_clean, l_clean = ops.encoder_heads_fwd(clean, blob, F, return_latent=True)
-        o, l = ops.encoder_heads_fwd(xb, blob, F, return_latent=True)
-    else:
-        o_clean, l_clean, _ = _wide_call("nlml_encoder_heads_fwd_wide", clean, B, blob, device, extra=(F, B, F), want_valid=False)
-        o, l, _ = _wide_call("nlml_encoder_heads_fwd_wide", xb, B, blob, device, extra=(F, B, F), want_valid=False)
+    o_clean, l_clean = ops.encoder_heads_fwd(clean, blob, F, return_latent=True)
+    o, l = ops.encoder_heads_fwd(xb, blob, F, return_latent=True)
     o32, l32 = ops.encoder_heads_fwd(xb, blob32, F, return_latent=True)
     fl = torch.from_numpy(flagged).to(device)
     assert torch.isfinite(o).all()
     assert torch.equal(o[~fl], o_clean[~fl]) and torch.equal(l[~fl], l_clean[~fl])          # neighbours, same tiles included, untouched
     assert torch.equal(o[fl], o32[fl]) and torch.equal(l[fl], l32[fl])                      # the strict parity kernel's bits
-    o_fused = ops.encoder_heads_fwd(xb, blob, F)
-    assert torch.equal(o, o_fused)                                                          # both paths, one answer
+    o_again = ops.encoder_heads_fwd(xb, blob, F)
+    assert torch.equal(o, o_again)                                                          # run to run
 
 
 # ---- round 5, second half: the trunk launch + streamed tail launch (encoder_heads_f16x2_w8.hip TRUNK = true, encoder_heads_f16x2_tailws.hip)

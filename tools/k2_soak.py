@@ -1,6 +1,6 @@
 """Randomised soak of the K2 implementations that must agree bit for bit (GPU box): for <minutes> minutes draw a batch size (weighted towards
 partial tiles and tile-count edges), a seed and a normalisation flag, and compare
-  strict-fast: fused eight-wave kernel, twice (determinism)  ==  layer-per-launch path  ==  128-face-tile path  (pose, latent, validity)
+  strict-fast: fused eight-wave kernel, twice (determinism)  ==  layer-per-launch path  ==  trunk + streamed-tail path  (pose, latent, validity)
   opt-in fast: fused four-wave kernel, twice                 ==  layer-per-launch path
   bf16 / f32 : fused kernel, twice (determinism)
 and, every tenth draw, the full 65,536-face batch three times (four tiles per CU: anything one tile leaves behind for the next shows up here).
@@ -21,14 +21,8 @@ L = _lib.lib()
 rng = np.random.default_rng(12345)
 
 
-def wide(raw, B, norm):
-    ws = torch.empty((max(16, L.nlml_encoder_heads_workspace_bytes(B, 1404)),), dtype=torch.uint8, device=dev)
-    out = torch.full((B, 3), float("nan"), dtype=torch.float32, device=dev)
-    lat = torch.empty((B, 9), dtype=torch.float32, device=dev)
-    val = torch.empty((B,), dtype=torch.uint8, device=dev)
-    _lib.check(L.nlml_landmarks_to_pose_wide(raw.data_ptr(), B, int(norm), blob["f16x2s"].data_ptr(), blob["f16x2s"].numel(), out.data_ptr(),
-                                             lat.data_ptr(), val.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "wide")
-    return out, lat, val.bool()
+def streamed(raw, B, norm):
+    return ops.landmarks_to_pose_streamed(raw, blob["f16x2s"], norm, return_latent=True, return_valid=True)
 
 
 def same(a, b):
@@ -64,8 +58,8 @@ while time.time() < t_end:
     for rep in range(3 if big else 1):
         again = ops.landmarks_to_pose(raw, blob["f16x2s"], norm, return_latent=True, return_valid=True)
         if not same(ref, again): print("DIFFERENT (strict fused, run to run)", tag); sys.exit(1)
+    if not same(ref, streamed(raw, B, norm)): print("DIFFERENT (strict fused vs trunk + streamed tail)", tag); sys.exit(1)
     if not big:
-        if not same(ref, wide(raw, B, norm)): print("DIFFERENT (strict fused vs 128-face-tile path)", tag); sys.exit(1)
         if B <= 16384:
             if not same(ref, ops.landmarks_to_pose_small(raw, blob["f16x2s"], norm, return_latent=True, return_valid=True)):
                 print("DIFFERENT (strict fused vs layer-per-launch)", tag); sys.exit(1)
