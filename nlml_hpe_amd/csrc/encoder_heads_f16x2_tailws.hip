@@ -19,7 +19,10 @@
 // per 256 faces = prologue 24 k (h3: 64 MB chip-wide at ~5.7 TB/s) + compute 138 k + barrier skew 38 k, against 104 k of pure MFMA time.
 // Variants measured and dropped: two accumulator chains per wave over 64-KB units (compiler-scheduled 206 k; pinned 207 k; pinned with
 // the previous job's epilogue in the MFMA shadows 255 k: the slices' dependent vector-ALU chains are longer than an MFMA slot); the two
-// waves of a SIMD half a job apart as two code instances (hipcc keeps 99 registers of one instance alive across the other: spills).
+// waves of a SIMD half a job apart as two code instances (hipcc keeps 99 registers of one instance alive across the other: spills); the
+// same half-unit skew in ONE instruction stream by moving only the barrier (waves 4-7 pass a unit's barrier behind its MFMAs, waves 0-3
+// behind its epilogue; two chains, 64-KB units; bit-identical) 193-194 k, with s_setprio(2) around the MFMA phases the same.  Every form
+// lands at 193-207 k cycles: what is left is not where any of them looked.
 //
 // Bits: per accumulator the same bias, the same K-ascending MFMA sequence ((w_lo, x_hi), (w_hi, x_lo), (w_hi, x_hi) per K step, single
 // accumulators as in the fused tail), the same epilogue arithmetic => bit-identical to tail_stages() (tests: the fused kernel and the
