@@ -22,7 +22,10 @@
 // waves of a SIMD half a job apart as two code instances (hipcc keeps 99 registers of one instance alive across the other: spills); the
 // same half-unit skew in ONE instruction stream by moving only the barrier (waves 4-7 pass a unit's barrier behind its MFMAs, waves 0-3
 // behind its epilogue; two chains, 64-KB units; bit-identical) 193-194 k, with s_setprio(2) around the MFMA phases the same.  Every form
-// lands at 193-207 k cycles: what is left is not where any of them looked.
+// lands at 193-207 k cycles -- also with every weight fragment read two K steps ahead by ds_read_b128 in inline asm and hand-counted
+// `s_waitcnt lgkmcnt(3)` in place of hipcc's `lgkmcnt(0)` in front of each MFMA (78 full drains per head), the encoder part pinned the same
+// way: 202 k.  What stays is the pair of waves on a SIMD: the older one is served first and finishes a 48-MFMA job in 2.5-3.0 k cycles
+// (52-62 per MFMA: its dependent chain), the younger in 4.2-4.6 k, and the unit lasts as long as the younger.
 //
 // Bits: per accumulator the same bias, the same K-ascending MFMA sequence ((w_lo, x_hi), (w_hi, x_lo), (w_hi, x_hi) per K step, single
 // accumulators as in the fused tail), the same epilogue arithmetic => bit-identical to tail_stages() (tests: the fused kernel and the
