@@ -1672,6 +1672,28 @@ def test_streamed_tail_path_flagged_faces_go_to_the_reevaluation_launch(head_sds
     assert torch.equal(o[fl], o32[fl]) and torch.equal(l[fl], l32[fl])
 
 
+def test_ops_landmarks_to_pose_streamed_wrapper(head_sds, device):
+    """The Python wrapper: cached hand-over buffer per (device, stream), a caller's own workspace, the three return forms, and the refusals
+    (CPU tensor, wrong shape, a blob of another mode)."""
+    from nlml_hpe_amd import _lib
+    sd = synth.encoder_state_dict(1404, seed=0)
+    blob = _blob_hx(sd, head_sds, device, "f16x2s")
+    raw = torch.from_numpy(synth.raw_landmarks(3000, seed=21)).to(device)
+    want = ops.landmarks_to_pose(raw, blob, True, return_latent=True, return_valid=True)
+    got = ops.landmarks_to_pose_streamed(raw, blob, True, return_latent=True, return_valid=True)
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+    assert torch.equal(ops.landmarks_to_pose_streamed(raw[:100], blob), want[0][:100])       # the cached buffer serves a smaller batch
+    ws = torch.empty((_lib.lib().nlml_encoder_heads_workspace_bytes(3000, 1404),), dtype=torch.uint8, device=device)
+    assert torch.equal(ops.landmarks_to_pose_streamed(raw, blob, workspace=ws), want[0])
+    with pytest.raises((_lib.NlmlError, ValueError, TypeError, RuntimeError)):
+        ops.landmarks_to_pose_streamed(raw.cpu(), blob)
+    with pytest.raises(ValueError):
+        ops.landmarks_to_pose_streamed(raw[:, :400], blob)
+    blob32 = torch.from_numpy(weights.pack_blob(sd, head_sds)).to(device)
+    with pytest.raises(_lib.NlmlError, match="F16X2S"):
+        ops.landmarks_to_pose_streamed(raw, blob32)
+
+
 needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL over xGMI (skips on the one-GPU box)")
 
 
