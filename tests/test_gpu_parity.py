@@ -1517,7 +1517,7 @@ def test_bench_two_rank_path_on_one_gpu(repo_root, device):
 
 # ---- round 5: the workspace-taking entry points, the 64-face-tile form of the f32 re-evaluation launch with flagged faces, the trunk + streamed-tail
 # path, and the RCCL tests that run by themselves on the first multi-GPU box.  (The 128-face-tile path these tests were first written for measured
-# slower than the fused kernel and was deleted at the round's end: DESIGN.md section 3, Appendix A.5.)
+# slower than the fused kernel and was deleted at the round's end: DESIGN.md section 3, DESIGN_APPENDIX.md A.5.)
 def _wide_call(fn_name, first, B, blob, device, *, want_latent=True, want_valid=True, extra=()):
     """One call of a workspace-taking C entry point (nlml_*_streamed / nlml_*_ws) -> (pose, latent, valid)."""
     from nlml_hpe_amd import _lib
