@@ -23,8 +23,7 @@ for _ in range(20):
                                                  ws.data_ptr(), ws.numel(), st), "streamed")
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().reshape(256, 8, 96).astype(np.int64)
-names = ["E3.0", "E3.1", "E3.2", "E3.3", "E4", "E5"] + [f"H{k}.{g}" for g in range(3) for k in
-                                                        ("0", "1a", "1b", "1c", "1d", "2a", "2b", "2c", "2d", "3", "4")]
+names = ["E3.01", "E3.23", "E4", "E5"] + [f"H{k}.{g}" for g in range(3) for k in ("0", "1a", "1b", "1c", "1d", "2ab", "2cd", "3", "4")]
 total = (s[:, :, 3 + 2 * (len(names) - 1)] - s[:, :, 0]).mean()
 print(f"kernel entry -> last barrier: {total:,.0f} cycles (mean over waves); prologue {(s[:, :, 1] - s[:, :, 0]).mean():,.0f}")
 prev = s[:, :, 1]
