@@ -147,8 +147,8 @@ int nlml_landmarks_to_pose_streamed(const float* raw, int64_t B, int normalize, 
 // ---- the forward with a caller-provided workspace: the fastest path for the batch size and the blob's mode -------------------------
 // (measured crossovers, tools/k2_crossover.py and bench.py extra.k2_batch_sweep)
 static const int64_t kSmallMax = 4096;     // split-f16 modes: up to here the layer-per-launch path over 64-face tiles
-// The trunk + streamed-tail path (encoder_heads_f16x2_tailws.hip) is bit-identical to the fused kernel and measured 1.2 % faster at 65,536
-// faces (0.805 against 0.815 ms, same box, alternating) -- inside the box-to-box spread, for a 64 MB workspace and a
+// The trunk + streamed-tail path (encoder_heads_f16x2_tailws.hip) is bit-identical to the fused kernel and measured 1.4-2.2 % faster at 65,536
+// faces (0.801 against 0.815 ms, same box, alternating) -- inside the box-to-box spread, for a 64 MB workspace and a
 // second big launch -- so the dispatcher does not pick it by itself.  NLML_K2_STREAMED_MIN=<faces> routes batches from that size
 // on through it (the explicit _streamed entry points always do).
 static int64_t streamed_min() {

@@ -359,7 +359,7 @@ _streamed_ws: dict = {}
 def landmarks_to_pose_streamed(raw: torch.Tensor, blob: torch.Tensor, normalize: bool = True, return_latent: bool = False,
                                return_valid: bool = False, workspace: torch.Tensor | None = None):
     """landmarks_to_pose (strict-fast blob only) as trunk launch + streamed tail launch + the f32 re-evaluation launch
-    (nlml_landmarks_to_pose_streamed): bit-identical to the fused kernel, measured 1.2 % faster at 65,536 faces; nothing calls it by default
+    (nlml_landmarks_to_pose_streamed): bit-identical to the fused kernel, measured 1.4-2.2 % faster at 65,536 faces; nothing calls it by default
     (DESIGN.md section 3).  The hand-over buffer (1 KB per face) is cached per device and stream like the layer-per-launch path's scratch."""
     _need_cuda(raw, "raw", torch.float32)
     _need_cuda(blob, "blob", torch.uint8)
