@@ -80,7 +80,8 @@ static_assert(TW_LDS <= 163840, "LDS map");
 // accumulator chains' worth of work at a time (a dependent v_mfma_f32_32x32x16_f16 chain issues every ~62 cycles, the pipe takes one
 // every 32: stamped with one chain per wave, 3.0 k cycles for the older wave of a SIMD and 4.6 k for the younger per 48 MFMAs each):
 //   E3 jobs (0,1) | E3 jobs (2,3) | E4 (both jobs) | E5 (one job of two blocks) |
-//   per head g: H0 (four jobs) | H1 jobs (0,1) | H1 jobs (2,3) | H2 jobs (0,1) | H2 jobs (2,3) | H3 (both jobs) | H4
+//   per head g: H0 (four jobs) | H1 job 0 | H1 job 1 | H1 job 2 | H1 job 3 (a job's two blocks = the two chains) | H2 jobs (0,1) | H2 jobs (2,3) |
+//   H3 (both jobs) | H4
 constexpr int TW_HEAD_UNITS = 9, TW_UNITS = 4 + 3 * TW_HEAD_UNITS;
 __device__ __forceinline__ void tw_unit(const HdrRegs& H, int idx, uint32_t& off, uint32_t& n16) {
   constexpr uint32_t J3 = stage_job_w16_const(ST_E3), J4 = stage_job_w16_const(ST_E4), J5 = stage_job_w16_const(ST_E5);
