@@ -167,7 +167,8 @@ int nlml_landmarks_to_pose_small(const float* raw, int64_t B, int normalize,
  * through the whole tail while the tail's 1.06 MB of weights pass through LDS once per 256 faces (csrc/encoder_heads_f16x2_tailws.hip)
  * -- in the fused kernel they stream once per 64 faces through thirteen barrier-separated stages on half the CU's waves.
  * MEASURED 1.4-2.2 % faster than the fused kernel at 65,536 faces (0.801 against 0.815 ms, same box; the trunk launch alone costs 0.90 of the
- * fused kernel = its share of the L2 -> CU bytes): inside the box-to-box spread, so nothing picks it by default
+ * fused kernel = its share of the L2 -> CU bytes; below ~60,000 faces the path LOSES: -5 % at 32,768, -16 % at 16,384): inside
+ * the box-to-box spread, so nothing picks it by default
  * (NLML_K2_STREAMED_MIN=<faces> makes the _ws entry points route batches from that size on through it).
  * Bit-identical to nlml_encoder_heads_fwd / nlml_landmarks_to_pose with the same blob.  Input layout: F % 4 == 0, rows 16-byte aligned
  * (ldx % 4 == 0) -- else NLML_E_BADARG.  `workspace`: nlml_encoder_heads_workspace_bytes(B, F) bytes, 16-byte aligned.
