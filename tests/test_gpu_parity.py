@@ -1694,6 +1694,45 @@ def test_ops_landmarks_to_pose_streamed_wrapper(head_sds, device):
         ops.landmarks_to_pose_streamed(raw, blob32)
 
 
+def test_ws_dispatcher_routes_large_batches_through_the_streamed_path_on_request(repo_root):
+    """NLML_K2_STREAMED_MIN=<faces> (read once per process): nlml_landmarks_to_pose_ws takes the trunk + streamed-tail path from that size on --
+    seen here as the launches it makes (the tail kernel's name in a rocprofv3-free way: the call must fail with a workspace that is
+    large enough for the layer-per-launch path but too small for the hand-over) -- and computes the fused kernel's bits."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch
+from nlml_hpe_amd import _lib, ops, synth, weights
+dev = torch.device("cuda:0")
+heads = weights.load_head_state_dicts(os.path.join(%r, "models"))
+blob = torch.from_numpy(weights.pack_blob(synth.encoder_state_dict(1404, seed=0), heads, _lib.MODE_F16X2S)).to(dev)
+L = _lib.lib()
+B = 9000
+raw = torch.from_numpy(synth.raw_landmarks(B, seed=4)).to(dev)
+want = ops.landmarks_to_pose(raw, blob, True)
+out = torch.empty((B, 3), dtype=torch.float32, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+ws = torch.empty((L.nlml_encoder_heads_workspace_bytes(B, 1404),), dtype=torch.uint8, device=dev)
+rc = L.nlml_landmarks_to_pose_ws(raw.data_ptr(), B, 1, blob.data_ptr(), blob.numel(), out.data_ptr(), None, None, ws.data_ptr(), ws.numel(), st)
+torch.cuda.synchronize()
+small = torch.empty((1 << 20,), dtype=torch.uint8, device=dev)      # 1 MB: less than the hand-over's 1 KB per face
+rc2 = L.nlml_landmarks_to_pose_ws(raw.data_ptr(), B, 1, blob.data_ptr(), blob.numel(), out.data_ptr(), None, None, small.data_ptr(), small.numel(), st)
+print("RESULT", rc, bool(torch.equal(want, out)) if rc == 0 else None, rc2, L.nlml_last_error().decode()[:60] if rc2 else "")
+""" % (repo_root, repo_root)
+    def run(env_extra):
+        env = {k: v for k, v in os.environ.items() if k != "NLML_K2_STREAMED_MIN"}
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0]
+    routed = run({"NLML_K2_STREAMED_MIN": "8192"})
+    assert routed.startswith("RESULT 0 True -1") and "workspace" in routed, routed      # streamed path: right bits, and it needs its hand-over buffer
+    plain = run({})
+    assert plain.startswith("RESULT 0 True 0"), plain                                    # fused kernel: ignores the workspace
+
+
 needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL over xGMI (skips on the one-GPU box)")
 
 
