@@ -259,6 +259,9 @@ __global__ __launch_bounds__(512) void tail_ws_kernel(TwArgs a) {
   // the counts match; unit k is read by both kinds between barriers k-1 and k, so the two-buffer DMA schedule is unchanged (unit k + 1 is
   // requested right behind barrier k - 1 by every wave and waited for -- vmcnt(0) -- in front of barrier k).  The conditional wraps nothing
   // but the barrier: no register is live on one side only (two code INSTANCES of the body made hipcc spill 99 registers).
+  // This is the gfx9 S_BARRIER's rule (it counts the workgroup's waves that have arrived, wherever each one's barrier instruction stands),
+  // not the HIP programming model's (every thread at the same __syncthreads()): the file refuses to build for anything but gfx950 (above),
+  // the bit-identity tests are the gate, and -DTW_NO_SKEW builds the model-conforming form (every wave's barrier behind E; same bits).
 #ifdef TW_NO_SKEW
   const bool late = false;
 #else
